@@ -1,0 +1,191 @@
+/* gsplat_hip.h -- C-ABI of libgsplat_hip.so: the MI355X (gfx950) render path behind the
+ * taichi_splatting operator API.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a caller-owned DEVICE buffer unless the name ends in _host; nothing is
+ *     allocated or freed inside the library; scratch comes from the caller (sizes below).
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *     all work is enqueued on it and no entry point synchronises the device.  Host-visible
+ *     counts (V, K) are written to device int32 words that the caller reads back itself.
+ *   - return value: 0 on success, negative GsStatus on failure; gs_last_error() returns a
+ *     thread-local message for the last failure on the calling thread.
+ *   - re-entrant, no global mutable state.
+ *   - f32 only (the reference's f64 instantiations exist for gradcheck only,
+ *     taichi_lib/__init__.py:8-14; f64 checks run against the CPU oracle in tests/).
+ *
+ * "replaces" lines cite the reference interface each entry point stands in for (paths relative
+ * to /root/reference/taichi_splatting/).  The reference-side binding is in INTEGRATION.md.
+ */
+#ifndef GSPLAT_HIP_H
+#define GSPLAT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum GsStatus {
+  GS_OK = 0,
+  GS_ERR_INVALID_ARGUMENT = -1,
+  GS_ERR_UNSUPPORTED = -2,   /* e.g. tile_size not in {8,16,32}, feature width > GS_MAX_FEATURES */
+  GS_ERR_LAUNCH = -3,        /* hipGetLastError() after a launch */
+  GS_ERR_SCRATCH_TOO_SMALL = -4
+} GsStatus;
+
+#define GS_MAX_FEATURES 32
+#define GS_MAX_SH_CHANNELS 8
+
+/* Mirrors RasterConfig (data_types.py:13-39) field for field. */
+typedef struct GsRasterConfig {
+  int32_t tile_size;            /* 8, 16 or 32 */
+  int32_t pixel_stride_x;       /* accepted, ignored: thread<->pixel mapping only (rasterizer/tiling.py:35-65) */
+  int32_t pixel_stride_y;
+  int32_t antialias;
+  int32_t use_alpha_blending;
+  int32_t compute_point_heuristic;
+  int32_t compute_visibility;
+  float clamp_margin;
+  float blur_cov;
+  float clamp_max_alpha;
+  float alpha_threshold;
+  float saturate_threshold;
+} GsRasterConfig;
+
+const char* gs_last_error(void);
+int gs_version(void);
+
+/* ------------------------------------------------------------------ projection (a2, a3) --
+ * replaces: perspective/projection.py:32-80 project_kernel + :146-149 (nonzero + gathers) and
+ * torch_lib/projection.py:120-123 ndc_depth (called renderer.py:189).
+ *
+ * Step 1 projects all n Gaussians into n-row staging buffers and counts the visible ones per
+ * 256-thread block; step 2 scans the block counts and compacts, in ascending index order, into
+ * buffers the caller sized for n rows (only the first V rows are written).  *num_visible
+ * (device int32) receives V.
+ *   T_camera_world: 16 floats row-major 4x4 (device), projection: [fx,fy,cx,cy] (device).
+ *   points: (V,7) [mean.xy, axis.xy, sigma.xy, alpha]; depth: (V) camera z; ndc_depth: (V)
+ *   = 1 - (1/z - (float)(1/far)) / (float)(1/near - 1/far)  (fixed f32 op order);
+ *   indexes: (V) int64 ascending; slot_of: (n) int32, compact row of Gaussian i or -1.
+ * scratch: gs_project_scratch_bytes(n).
+ */
+int64_t gs_project_scratch_bytes(int64_t n);
+int gs_project_fwd(int64_t n, const float* position, const float* log_scaling, const float* rotation,
+                   const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
+                   int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
+                   float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
+                   void* scratch, int64_t scratch_bytes, void* stream);
+
+/* replaces: perspective/projection.py:84-118 indexed_project_kernel.grad (Taichi autodiff,
+ * :166-185).  Hand-derived adjoint.  Dense gradients (rows of culled Gaussians are zero);
+ * d_T_camera_world is 16 floats (last row zero) and d_projection 4 floats, summed over the
+ * visible set (the reference sums its per-point expanded copies, :212-213).  Either may be NULL.
+ * grad_points (V,7), grad_depth (V) may be NULL (treated as zero).
+ * scratch: gs_project_bwd_scratch_bytes(n) (per-block camera partials; unused when both camera
+ * outputs are NULL).
+ */
+int64_t gs_project_bwd_scratch_bytes(int64_t n);
+int gs_project_bwd(int64_t n, int64_t v, const float* position, const float* log_scaling, const float* rotation,
+                   const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
+                   int32_t height, const GsRasterConfig* cfg, const int32_t* slot_of, const float* grad_points,
+                   const float* grad_depth, float* d_position, float* d_log_scaling, float* d_rotation,
+                   float* d_alpha_logit, float* d_T_camera_world, float* d_projection, void* scratch,
+                   int64_t scratch_bytes, void* stream);
+
+/* ------------------------------------------------------------ spherical harmonics (a4) --
+ * replaces: spherical_harmonics.py:118-134 evaluate_sh_at_kernel (+ .grad, :154-161).
+ * params (n,C,D) D=(degree+1)^2, degree 0..3, C <= GS_MAX_SH_CHANNELS; positions (n,3);
+ * indexes (v) int64 (may repeat); camera_pos 3 floats (device); out (v,C).
+ * Backward: d_params (n,C,D) and d_positions (n,3) are zero-filled inside, then written.  When
+ * indexes_unique != 0 (the list came from gs_project_fwd) rows are written with plain stores;
+ * otherwise with float atomics (the reference test passes repeated indexes,
+ * tests/test_spherical_harmonics.py:27).  d_camera_pos 3 floats.  d_positions / d_camera_pos may
+ * be NULL.
+ */
+int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
+              const int64_t* indexes, const float* camera_pos, float* out, void* stream);
+int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
+              const int64_t* indexes, int32_t indexes_unique, const float* camera_pos, const float* grad_out,
+              float* d_params, float* d_positions, float* d_camera_pos, void* stream);
+
+/* --------------------------------------------------------------- tile mapper (a5 - a10) --
+ * Fused path (what map_to_tiles runs).  replaces mapper/tile_mapper.py:169-196 as a whole:
+ *   gs_map_prepare: OBB tile query per Gaussian (taichi_lib/grid_query.py:10-91) -> per-tile
+ *     histogram -> exclusive scan -> tile_ranges (T,2) (empty tiles (0,0), :186) and
+ *     counts_out[0] = K, counts_out[1] = largest tile population (device int32[2]).
+ *   gs_map_finish: re-runs the query, buckets (depth key, index) pairs by tile, then sorts each
+ *     tile's bucket on the composite (depth bits, Gaussian index): exactly the order of the
+ *     reference's stable 48-bit radix sort of (tile<<32 | depth bits) in generation order
+ *     (:34-40, :113-155).  overlap_to_point (K) int32; sorted_keys (K) uint64, optional (NULL),
+ *     receives the reference's key layout for verification.
+ * image size is the UNPADDED (width,height); padding to a tile multiple is internal (:18-22).
+ * depth: (v) f32, non-negative (ndc depth).  use_depth16: key layout of :53-59.
+ * scratch: gs_map_scratch_bytes(v, num_tiles); pair_scratch: K * 8 bytes.
+ */
+int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
+int gs_map_prepare(int64_t v, const float* points, int32_t width, int32_t height, const GsRasterConfig* cfg,
+                   int32_t* tile_ranges, int32_t* counts_out, void* scratch, int64_t scratch_bytes, void* stream);
+int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const float* points, const float* depth,
+                  int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
+                  const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys, void* pair_scratch,
+                  void* scratch, int64_t scratch_bytes, void* stream);
+
+/* Reference-shaped primitives (the same pipeline stage by stage, as the reference runs it). */
+
+/* replaces: mapper/tile_mapper.py:74-84 tile_overlaps_kernel.  counts (v) int32. */
+int gs_tile_count(int64_t v, const float* points, int32_t width, int32_t height, const GsRasterConfig* cfg,
+                  int32_t* counts, void* stream);
+/* replaces: cuda_lib.full_cumsum (cuda_lib/__init__.py:16-25, full_cumsum.cu:17-67).
+ * out has n+1 entries; out[n] is the total (read it back from there).  scratch: gs_cumsum_scratch_bytes(n). */
+int64_t gs_cumsum_scratch_bytes(int64_t n);
+int gs_full_cumsum_i32(int64_t n, const int32_t* in, int32_t* out, void* scratch, int64_t scratch_bytes,
+                       void* stream);
+/* replaces: mapper/tile_mapper.py:113-144 generate_sort_keys_kernel.  keys (K) uint64 (the u32
+ * depth16 key is zero-extended), values (K) int32, in generation order. */
+int gs_tile_emit_keys(int64_t v, const float* points, const float* depth, const int32_t* offsets, int32_t width,
+                      int32_t height, const GsRasterConfig* cfg, int32_t use_depth16, uint64_t* keys,
+                      int32_t* values, void* stream);
+/* replaces: cuda_lib.radix_sort_pairs (cuda_lib/__init__.py:28-35, radix_sort_pairs.cu:8-70):
+ * stable ascending LSD radix sort of (key,value) pairs on key bits [begin_bit,end_bit)
+ * (end_bit <= 0 means all bits).  key_bytes 4 or 8.  Outputs in keys_out / values_out; the inputs
+ * are preserved.  scratch: gs_sort_scratch_bytes(k, key_bytes). */
+int64_t gs_sort_scratch_bytes(int64_t k, int32_t key_bytes);
+int gs_radix_sort_pairs(int64_t k, int32_t key_bytes, const void* keys_in, const int32_t* values_in, void* keys_out,
+                        int32_t* values_out, int32_t begin_bit, int32_t end_bit, void* scratch,
+                        int64_t scratch_bytes, void* stream);
+/* replaces: mapper/tile_mapper.py:91-110 find_ranges_kernel (+ zero-init :186). */
+int gs_find_ranges(int64_t k, const uint64_t* sorted_keys, int32_t use_depth16, int64_t num_tiles,
+                   int32_t* tile_ranges, void* stream);
+
+/* ------------------------------------------------------------- rasterizer (a11 - a13) --
+ * replaces: rasterizer/forward.py:25-137 _forward_kernel (allocation contract of
+ * rasterizer/function.py:43-76).  points (V,7), features (V,F), tile_ranges (T,2) int32 with
+ * T = ceil(W/ts)*ceil(H/ts), overlap_to_point (K) int32.  image (H,W,F), alpha (H,W).
+ * visibility (V) must be zero-filled by the caller when cfg->compute_visibility, else may be NULL.
+ */
+int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
+                  const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
+                  int32_t height, const GsRasterConfig* cfg, float* image, float* alpha, float* visibility,
+                  void* stream);
+
+/* replaces: rasterizer/backward.py:53-228 _backward_kernel.
+ * Per-Gaussian gradients are accumulated with float atomics into ONE row per Gaussian,
+ * grad_rows (V, gs_grad_row_floats(F)), 64-byte aligned rows:
+ *   [0..7) d(mean.xy, axis.xy, sigma.xy, alpha), [7..7+F) d(features), [7+F, 8+F) point heuristics.
+ * (One 64-B segment per (tile, splat) is the shape the memory-side float atomics run fastest at.)
+ * The caller zero-fills grad_rows.  gs_raster_bwd_unpack splits rows into the reference's
+ * separate tensors (rasterizer/function.py:84-91); any output may be NULL.
+ */
+int32_t gs_grad_row_floats(int32_t num_features);
+int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
+                  const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
+                  int32_t height, const GsRasterConfig* cfg, const float* image, const float* grad_image,
+                  float* grad_rows, void* stream);
+int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
+                         float* grad_features, float* point_heuristic, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSPLAT_HIP_H */

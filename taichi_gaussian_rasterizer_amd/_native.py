@@ -1,0 +1,131 @@
+"""ctypes binding of libgsplat_hip.so (include/gsplat_hip.h).
+
+The HIP library is the ONLY compute backend of this package: there is no CPU fallback and no
+torch re-implementation behind these calls.  If the shared library is missing, or a tensor is not
+a float32 CUDA(HIP) tensor, the call raises -- it never silently routes elsewhere.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import POINTER, c_double, c_float, c_int32, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+class GsRasterConfig(ctypes.Structure):
+    """include/gsplat_hip.h GsRasterConfig (mirrors reference data_types.py:13-39)."""
+    _fields_ = [("tile_size", c_int32), ("pixel_stride_x", c_int32), ("pixel_stride_y", c_int32),
+                ("antialias", c_int32), ("use_alpha_blending", c_int32), ("compute_point_heuristic", c_int32),
+                ("compute_visibility", c_int32), ("clamp_margin", c_float), ("blur_cov", c_float),
+                ("clamp_max_alpha", c_float), ("alpha_threshold", c_float), ("saturate_threshold", c_float)]
+
+
+_CFG = POINTER(GsRasterConfig)
+_P = c_void_p
+_I32, _I64, _F64 = c_int32, c_int64, c_double
+
+# name -> (restype, argtypes); every symbol declared in include/gsplat_hip.h
+SIGNATURES = {
+    "gs_last_error": (ctypes.c_char_p, []),
+    "gs_version": (ctypes.c_int, []),
+    "gs_project_scratch_bytes": (_I64, [_I64]),
+    "gs_project_fwd": (ctypes.c_int, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _F64, _F64, _CFG, _P, _P, _P, _P, _P,
+                                       _P, _P, _I64, _P]),
+    "gs_project_bwd_scratch_bytes": (_I64, [_I64]),
+    "gs_project_bwd": (ctypes.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _P,
+                                       _P, _P, _P, _P, _I64, _P]),
+    "gs_sh_fwd": (ctypes.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P]),
+    "gs_map_scratch_bytes": (_I64, [_I64, _I64]),
+    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P, _P, _I64, _P]),
+    "gs_map_finish": (ctypes.c_int, [_I64, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    "gs_tile_count": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P]),
+    "gs_cumsum_scratch_bytes": (_I64, [_I64]),
+    "gs_full_cumsum_i32": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _P]),
+    "gs_tile_emit_keys": (ctypes.c_int, [_I64, _P, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P]),
+    "gs_sort_scratch_bytes": (_I64, [_I64, _I32]),
+    "gs_radix_sort_pairs": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, _P]),
+    "gs_find_ranges": (ctypes.c_int, [_I64, _P, _I32, _I64, _P, _P]),
+    "gs_raster_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P]),
+    "gs_grad_row_floats": (_I32, [_I32]),
+    "gs_raster_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P]),
+    "gs_raster_bwd_unpack": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _P]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, jobs: int = 6) -> str:
+    """Compile libgsplat_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, f"-j{jobs}"]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    res = subprocess.run(args, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError(f"building libgsplat_hip.so failed:\n{res.stdout[-4000:]}\n{res.stderr[-4000:]}")
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """Load the HIP library; raise loudly if it is not there (no fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is the only backend of taichi_gaussian_rasterizer_amd. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C taichi_gaussian_rasterizer_amd/csrc`).")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gs_last_error().decode("utf-8", "replace")
+        if rc == -2:
+            raise NotImplementedError(f"{what}: {msg}")
+        if rc == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+
+def make_config(config) -> GsRasterConfig:
+    return GsRasterConfig(
+        int(config.tile_size), int(config.pixel_stride[0]), int(config.pixel_stride[1]), int(config.antialias),
+        int(config.use_alpha_blending), int(config.compute_point_heuristic),
+        int(config.compute_visibility or config.compute_point_heuristic), float(config.clamp_margin),
+        float(config.blur_cov), float(config.clamp_max_alpha), float(config.alpha_threshold),
+        float(config.saturate_threshold))
+
+
+def require_device(*tensors: torch.Tensor, dtype=torch.float32, what="tensor") -> None:
+    """The operators run on MI355X only.  Anything else is an error, not a fallback."""
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                f"{what}: got a {t.device.type} tensor; taichi_gaussian_rasterizer_amd runs on a HIP device only "
+                "(there is no CPU path in the product; the CPU oracle lives in oracle/ for tests)")
+        if dtype is not None and t.dtype != dtype:
+            raise TypeError(f"{what}: expected {dtype}, got {t.dtype} (the HIP kernels are float32; the reference's "
+                            "float64 instantiations exist for gradcheck only)")
+
+
+def ptr(t) -> c_void_p:
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def stream() -> c_void_p:
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,471 @@
+// mapper.hip -- tile-overlap cull, per-tile bucketing and per-tile depth sort
+// (reference mapper/tile_mapper.py:74-196, taichi_lib/grid_query.py:10-91).
+//
+// COMPILED WITH -ffp-contract=off.  Every f32 operation of the grid query is a single correctly
+// rounded IEEE op in the same order as oracle/gsplat_oracle.cpp, and the logarithm is
+// gs_det_logf (include/gs_detmath.h), so the integer results -- which tiles a splat touches, the
+// sort keys, the order inside every tile -- are bit-identical to the CPU oracle.
+//
+// Fused path (gs_map_prepare / gs_map_finish), designed for MI355X rather than around a
+// library radix sort:
+//   count   : 1 lane per Gaussian, OBB query, one no-return int atomic per accepted tile into a
+//             T-entry histogram (T <= 65536 words: L2-resident).
+//   scan    : single workgroup exclusive scan of the histogram -> tile_ranges, cursors, K, max.
+//   emit    : the query again; slot = returning atomic on the tile's cursor; writes the 64-bit
+//             composite (depth key << 32 | gaussian index) into the tile's bucket.
+//   sort    : one workgroup per tile sorts its bucket in LDS (bitonic on the composite key).
+//             The composite makes the result independent of the atomic arrival order and equal
+//             to the reference's stable radix sort of (tile << 32 | depth) in generation order.
+// HBM traffic: K*8 B written by emit, K*8 B read + K*4 B written by sort, against
+// 6 passes * 2 * 12 B * K for the reference's Onesweep sort (profiles/bicycle_2048.txt:7).
+//
+// The reference-shaped primitives (gs_tile_count, gs_full_cumsum_i32, gs_tile_emit_keys,
+// gs_find_ranges; gs_radix_sort_pairs lives in radix_sort.hip) run the reference's own stage
+// sequence and are used to cross-check the fused path.
+
+#include "gs_common.h"
+#include "../../include/gs_detmath.h"
+
+namespace {
+
+struct GridQuery {
+  float ib00, ib01, ib10, ib11;
+  float rel_min_x, rel_min_y;
+  int min_tx, min_ty, span_x, span_y;
+};
+
+// taichi_lib/grid_query.py:73-91 (obb_grid_query) + :10-27 (tile_ranges)
+__device__ __forceinline__ GridQuery grid_query(const float* g, int Wp, int Hp, int tile_size, float alpha_thr) {
+  GridQuery q;
+  const float mx = g[0], my = g[1], ax = g[2], ay = g[3], sgx = g[4], sgy = g[5], alpha = g[6];
+  if (!(alpha > alpha_thr)) {  // explicit cull; the reference yields NaN bounds here (SURVEY 8a')
+    q.ib00 = q.ib01 = q.ib10 = q.ib11 = q.rel_min_x = q.rel_min_y = 0.f;
+    q.min_tx = q.min_ty = q.span_x = q.span_y = 0;
+    return q;
+  }
+  const float gscale = __fsqrt_rn(2.0f * gs_det_logf(__fdiv_rn(alpha, alpha_thr)));
+  const float sx = sgx * gscale, sy = sgy * gscale;
+  const float a2x = -ay, a2y = ax;
+  const float v1x = ax * sx, v1y = ay * sx, v2x = a2x * sy, v2y = a2y * sy;
+  const float ex = __fsqrt_rn(v1x * v1x + v2x * v2x), ey = __fsqrt_rn(v1y * v1y + v2y * v2y);
+  const float lox = mx - ex, loy = my - ey, hix = mx + ex, hiy = my + ey;
+  q.ib00 = __fdiv_rn(ax, sx); q.ib01 = __fdiv_rn(ay, sx); q.ib10 = __fdiv_rn(a2x, sy); q.ib11 = __fdiv_rn(a2y, sy);
+  const float ts = float(tile_size);
+  const int max_tx = (Wp - 1) / tile_size, max_ty = (Hp - 1) / tile_size;
+  int min_tx = int(floorf(__fdiv_rn(lox, ts))), min_ty = int(floorf(__fdiv_rn(loy, ts)));
+  min_tx = max(min_tx, 0); min_ty = max(min_ty, 0);
+  int hi_tx = int(ceilf(__fdiv_rn(hix, ts))), hi_ty = int(ceilf(__fdiv_rn(hiy, ts)));
+  hi_tx = min(max(hi_tx, min_tx + 1), max_tx + 1);
+  hi_ty = min(max(hi_ty, min_ty + 1), max_ty + 1);
+  q.min_tx = min_tx; q.min_ty = min_ty;
+  q.span_x = max(hi_tx - min_tx, 0); q.span_y = max(hi_ty - min_ty, 0);
+  q.rel_min_x = float(min_tx * tile_size) - mx;
+  q.rel_min_y = float(min_ty * tile_size) - my;
+  return q;
+}
+
+// taichi_lib/grid_query.py:30-43 (separates_bbox) / :58-61 (test_tile)
+__device__ __forceinline__ bool test_tile(const GridQuery& q, int u, int v, int tile_size) {
+  const float lx = q.rel_min_x + float(u * tile_size), ly = q.rel_min_y + float(v * tile_size);
+  const float ux = lx + float(tile_size), uy = ly + float(tile_size);
+  {
+    const float t0 = q.ib00 * lx + q.ib01 * ly, t1 = q.ib00 * ux + q.ib01 * ly;
+    const float t2 = q.ib00 * ux + q.ib01 * uy, t3 = q.ib00 * lx + q.ib01 * uy;
+    const float mn = fminf(fminf(t0, t1), fminf(t2, t3)), mxv = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+    if (mn > 1.0f || mxv < -1.0f) return false;
+  }
+  {
+    const float t0 = q.ib10 * lx + q.ib11 * ly, t1 = q.ib10 * ux + q.ib11 * ly;
+    const float t2 = q.ib10 * ux + q.ib11 * uy, t3 = q.ib10 * lx + q.ib11 * uy;
+    const float mn = fminf(fminf(t0, t1), fminf(t2, t3)), mxv = fmaxf(fmaxf(t0, t1), fmaxf(t2, t3));
+    if (mn > 1.0f || mxv < -1.0f) return false;
+  }
+  return true;
+}
+
+// mapper/tile_mapper.py:34-40 (32-bit depth) / :53-59 (16-bit depth): the depth part only
+__device__ __forceinline__ uint32_t depth_key(float depth, bool depth16) {
+  if (!depth16) return gs_f32_bits(depth);
+  const float d = depth < 0.f ? 0.f : (depth > 1.f ? 1.f : depth);
+  return uint32_t(d * 65535.0f);
+}
+
+struct MapArgs {
+  const float* points;
+  const float* depth;
+  int64_t v;
+  int Wp, Hp, tile_size, tiles_wide;
+  float thr;
+  int depth16;
+};
+
+// ---- fused path -------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void map_count_kernel(MapArgs a, int* tile_hist) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.v) return;
+  const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
+  for (int ty = 0; ty < q.span_y; ++ty)
+    for (int tx = 0; tx < q.span_x; ++tx)
+      if (test_tile(q, tx, ty, a.tile_size))
+        atomicAdd(tile_hist + (tx + q.min_tx) + (ty + q.min_ty) * a.tiles_wide, 1);
+}
+
+// single-workgroup exclusive scan over the T-entry histogram (T <= 65536 + slack)
+__global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
+                                                        int* cursors, int* counts_out) {
+  __shared__ int s_part[1024];
+  __shared__ int s_max[1024];
+  const int t = threadIdx.x;
+  const int per = (num_tiles + 1023) / 1024;
+  const int lo = t * per, hi = min(lo + per, num_tiles);
+  int sum = 0, mx = 0;
+  for (int i = lo; i < hi; ++i) { const int c = tile_hist[i]; sum += c; mx = max(mx, c); }
+  s_part[t] = sum;
+  s_max[t] = mx;
+  __syncthreads();
+  // Hillis-Steele inclusive scan of the 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
+    int vsum = s_part[t], vmax = s_max[t];
+    if (t >= off) { vsum += s_part[t - off]; vmax = max(vmax, s_max[t - off]); }
+    __syncthreads();
+    s_part[t] = vsum; s_max[t] = vmax;
+    __syncthreads();
+  }
+  int run = s_part[t] - sum;  // exclusive prefix of this thread's chunk
+  for (int i = lo; i < hi; ++i) {
+    const int c = tile_hist[i];
+    tile_ranges[i] = c > 0 ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
+    cursors[i] = run;
+    run += c;
+  }
+  if (t == 1023) { counts_out[0] = s_part[1023]; counts_out[1] = s_max[1023]; }
+}
+
+__global__ __launch_bounds__(256) void map_emit_kernel(MapArgs a, int* cursors, uint64_t* pairs) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.v) return;
+  const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
+  if (q.span_x == 0 || q.span_y == 0) return;
+  const uint64_t pair = (uint64_t(depth_key(a.depth[i], a.depth16 != 0)) << 32) | uint64_t(uint32_t(i));
+  for (int ty = 0; ty < q.span_y; ++ty)
+    for (int tx = 0; tx < q.span_x; ++tx)
+      if (test_tile(q, tx, ty, a.tile_size)) {
+        const int slot = atomicAdd(cursors + (tx + q.min_tx) + (ty + q.min_ty) * a.tiles_wide, 1);
+        pairs[slot] = pair;
+      }
+}
+
+// One workgroup per tile.  n <= CAP: bitonic sort in LDS.  n > CAP: the same network in place in
+// global memory (rare: more than CAP splats on one tile); a workgroup lives on one CU, so its own
+// global writes are visible to it after __syncthreads().
+// The network is the direction-free bitonic formulation: each merge of width k starts with a
+// mirror step (partner i ^ (k-1)) and continues with partners i ^ j, j = k/4 .. 1; every
+// compare-exchange puts the minimum at the lower index.  Elements at index >= n are virtual +inf:
+// they never move, so no padding is stored and n need not be a power of two.
+template <int THREADS>
+__device__ __forceinline__ void bitonic_sort(uint64_t* data, int n, int t) {
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int k = 2; k <= np2; k <<= 1) {
+    for (int i = t; i < n; i += THREADS) {
+      const int l = i ^ (k - 1);
+      if (l > i && l < n) {
+        const uint64_t x = data[i], y = data[l];
+        if (x > y) { data[i] = y; data[l] = x; }
+      }
+    }
+    __syncthreads();
+    for (int j = k >> 2; j > 0; j >>= 1) {
+      for (int i = t; i < n; i += THREADS) {
+        const int l = i ^ j;
+        if (l > i && l < n) {
+          const uint64_t x = data[i], y = data[l];
+          if (x > y) { data[i] = y; data[l] = x; }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int THREADS, int CAP>
+__global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const int2* tile_ranges, uint64_t* pairs,
+                                                            int* o2p, uint64_t* keys_out, int depth16) {
+  __shared__ uint64_t s_key[CAP];
+  const int tile = gs_xcd_remap(blockIdx.x, num_tiles);
+  if (tile < 0) return;
+  const int2 r = tile_ranges[tile];
+  const int n = r.y - r.x;
+  if (n <= 0) return;
+  uint64_t* seg = pairs + r.x;
+  const int t = threadIdx.x;
+  uint64_t* data = seg;
+  if (n <= CAP) {
+    for (int i = t; i < n; i += THREADS) s_key[i] = seg[i];
+    data = s_key;
+  }
+  __syncthreads();
+  bitonic_sort<THREADS>(data, n, t);
+  const int shift = depth16 ? 16 : 32;
+  for (int i = t; i < n; i += THREADS) {
+    const uint64_t kv = data[i];
+    o2p[r.x + i] = int(uint32_t(kv));
+    if (keys_out) keys_out[r.x + i] = (kv >> 32) | (uint64_t(uint32_t(tile)) << shift);
+  }
+}
+
+// ---- reference-shaped primitives ----------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_count_kernel(MapArgs a, int* counts) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.v) return;
+  const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
+  int c = 0;
+  for (int ty = 0; ty < q.span_y; ++ty)
+    for (int tx = 0; tx < q.span_x; ++tx) c += test_tile(q, tx, ty, a.tile_size) ? 1 : 0;
+  counts[i] = c;
+}
+
+__global__ __launch_bounds__(256) void tile_emit_keys_kernel(MapArgs a, const int* offsets, uint64_t* keys,
+                                                             int* values) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= a.v) return;
+  const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
+  int64_t k = offsets[i];
+  const uint64_t dk = depth_key(a.depth[i], a.depth16 != 0);
+  const int shift = a.depth16 ? 16 : 32;
+  // ti.ndrange(span.x, span.y): x outer, y inner (tile_mapper.py:134)
+  for (int tx = 0; tx < q.span_x; ++tx)
+    for (int ty = 0; ty < q.span_y; ++ty)
+      if (test_tile(q, tx, ty, a.tile_size)) {
+        const int tile_id = (tx + q.min_tx) + (ty + q.min_ty) * a.tiles_wide;
+        keys[k] = dk | (uint64_t(uint32_t(tile_id)) << shift);
+        values[k] = int(i);
+        ++k;
+      }
+}
+
+__global__ __launch_bounds__(256) void find_ranges_kernel(int64_t k, const uint64_t* keys, int shift, int* ranges) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= k) return;
+  const int64_t t = int64_t(keys[i] >> shift);
+  if (i == 0 || int64_t(keys[i - 1] >> shift) != t) ranges[2 * t] = int(i);
+  if (i + 1 == k || int64_t(keys[i + 1] >> shift) != t) ranges[2 * t + 1] = int(i + 1);
+}
+
+// block-level exclusive scan, 3 kernels: (1) per-block sums, (2) scan of sums (one block),
+// (3) per-block scan + offset.  1024 elements per block (256 threads x 4).
+constexpr int SCAN_BLOCK = 1024;
+
+__global__ __launch_bounds__(256) void scan_block_sums(int64_t n, const int* in, int* sums) {
+  __shared__ int s[256];
+  const int64_t base = int64_t(blockIdx.x) * SCAN_BLOCK;
+  int acc = 0;
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + threadIdx.x * 4 + e;
+    if (i < n) acc += in[i];
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
+}
+
+__global__ __launch_bounds__(1024) void scan_sums(int nb, int* sums) {  // exclusive, in place, single block
+  __shared__ int s[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nb ? sums[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      int x = s[threadIdx.x];
+      if (threadIdx.x >= off) x += s[threadIdx.x - off];
+      __syncthreads();
+      s[threadIdx.x] = x;
+      __syncthreads();
+    }
+    if (i < nb) sums[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += s[1023];
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void scan_apply(int64_t n, const int* in, const int* sums, int* out) {
+  __shared__ int s[256];
+  const int64_t base = int64_t(blockIdx.x) * SCAN_BLOCK;
+  int v[4], acc = 0;
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + threadIdx.x * 4 + e;
+    v[e] = i < n ? in[i] : 0;
+    acc += v[e];
+  }
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    int x = s[threadIdx.x];
+    if (threadIdx.x >= off) x += s[threadIdx.x - off];
+    __syncthreads();
+    s[threadIdx.x] = x;
+    __syncthreads();
+  }
+  int run = sums[blockIdx.x] + s[threadIdx.x] - acc;
+  for (int e = 0; e < 4; ++e) {
+    const int64_t i = base + threadIdx.x * 4 + e;
+    if (i < n) out[i] = run;
+    run += v[e];
+    if (i == n - 1) out[n] = run;  // the total, appended (full_cumsum.cu:36-41)
+  }
+}
+
+int fill_args(MapArgs& a, int64_t v, const float* points, const float* depth, int width, int height,
+              const GsRasterConfig* cfg, int depth16) {
+  if (int rc = gs_check_cfg(cfg)) return rc;
+  GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "mapper: image size %dx%d", width, height);
+  GS_REQUIRE(v >= 0 && v < (int64_t(1) << 31), GS_ERR_INVALID_ARGUMENT, "mapper: %lld gaussians", (long long)v);
+  const int ts = cfg->tile_size;
+  a.points = points; a.depth = depth; a.v = v;
+  a.Wp = int(gs_div_up(width, ts)) * ts;  // pad_to_tile, tile_mapper.py:18-22
+  a.Hp = int(gs_div_up(height, ts)) * ts;
+  a.tile_size = ts;
+  a.tiles_wide = a.Wp / ts;
+  a.thr = cfg->alpha_threshold;
+  a.depth16 = depth16;
+  return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
+  (void)v;
+  return gs_align_up(num_tiles * 4, 256) * 2;  // histogram + cursors
+}
+
+extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int32_t height,
+                              const GsRasterConfig* cfg, int32_t* tile_ranges, int32_t* counts_out, void* scratch,
+                              int64_t scratch_bytes, void* stream) {
+  MapArgs a;
+  if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0)) return rc;
+  const int num_tiles = a.tiles_wide * (a.Hp / a.tile_size);
+  GS_REQUIRE(tile_ranges && counts_out && scratch, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: NULL buffer");
+  GS_REQUIRE(scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_map_prepare: scratch %lld < %lld bytes", (long long)scratch_bytes,
+             (long long)gs_map_scratch_bytes(v, num_tiles));
+  GS_REQUIRE(num_tiles <= (1 << 20), GS_ERR_UNSUPPORTED, "gs_map_prepare: %d tiles (limit 2^20)", num_tiles);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* hist = static_cast<int*>(scratch);
+  int* cursors = hist + gs_align_up(int64_t(num_tiles) * 4, 256) / 4;
+  if (hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) != hipSuccess) {
+    gs_set_error("gs_map_prepare: hipMemsetAsync failed");
+    return GS_ERR_LAUNCH;
+  }
+  if (v > 0) {
+    GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
+    hipLaunchKernelGGL(map_count_kernel, dim3(unsigned(gs_div_up(v, 256))), dim3(256), 0, s, a, hist);
+    GS_CHECK_LAUNCH("gs_map_prepare/count");
+  }
+  hipLaunchKernelGGL(map_scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist,
+                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out);
+  GS_CHECK_LAUNCH("gs_map_prepare/scan");
+  return GS_OK;
+}
+
+extern "C" int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const float* points, const float* depth,
+                             int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
+                             const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys,
+                             void* pair_scratch, void* scratch, int64_t scratch_bytes, void* stream) {
+  MapArgs a;
+  if (int rc = fill_args(a, v, points, depth, width, height, cfg, use_depth16)) return rc;
+  if (k == 0 || v == 0) return GS_OK;
+  const int num_tiles = a.tiles_wide * (a.Hp / a.tile_size);
+  GS_REQUIRE(points && depth && tile_ranges && overlap_to_point && pair_scratch && scratch, GS_ERR_INVALID_ARGUMENT,
+             "gs_map_finish: NULL buffer");
+  GS_REQUIRE(scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_map_finish: scratch too small");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* cursors = static_cast<int*>(scratch) + gs_align_up(int64_t(num_tiles) * 4, 256) / 4;
+  uint64_t* pairs = static_cast<uint64_t*>(pair_scratch);
+  hipLaunchKernelGGL(map_emit_kernel, dim3(unsigned(gs_div_up(v, 256))), dim3(256), 0, s, a, cursors, pairs);
+  GS_CHECK_LAUNCH("gs_map_finish/emit");
+  const int grid = 8 * int(gs_div_up(num_tiles, 8));
+  const int2* r = reinterpret_cast<const int2*>(tile_ranges);
+  if (max_tile_count <= 512)
+    hipLaunchKernelGGL((tile_sort_kernel<64, 512>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
+                       sorted_keys, use_depth16);
+  else if (max_tile_count <= 2048)
+    hipLaunchKernelGGL((tile_sort_kernel<256, 2048>), dim3(grid), dim3(256), 0, s, num_tiles, r, pairs,
+                       overlap_to_point, sorted_keys, use_depth16);
+  else
+    hipLaunchKernelGGL((tile_sort_kernel<1024, 8192>), dim3(grid), dim3(1024), 0, s, num_tiles, r, pairs,
+                       overlap_to_point, sorted_keys, use_depth16);
+  GS_CHECK_LAUNCH("gs_map_finish/sort");
+  return GS_OK;
+}
+
+extern "C" int gs_tile_count(int64_t v, const float* points, int32_t width, int32_t height,
+                             const GsRasterConfig* cfg, int32_t* counts, void* stream) {
+  MapArgs a;
+  if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0)) return rc;
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(points && counts, GS_ERR_INVALID_ARGUMENT, "gs_tile_count: NULL buffer");
+  hipLaunchKernelGGL(tile_count_kernel, dim3(unsigned(gs_div_up(v, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a, counts);
+  GS_CHECK_LAUNCH("gs_tile_count");
+  return GS_OK;
+}
+
+extern "C" int64_t gs_cumsum_scratch_bytes(int64_t n) { return gs_align_up((gs_div_up(n, SCAN_BLOCK) + 1) * 4, 256); }
+
+extern "C" int gs_full_cumsum_i32(int64_t n, const int32_t* in, int32_t* out, void* scratch, int64_t scratch_bytes,
+                                  void* stream) {
+  GS_REQUIRE(n >= 0 && out, GS_ERR_INVALID_ARGUMENT, "gs_full_cumsum_i32: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(out, 0, 4, s) != hipSuccess) { gs_set_error("gs_full_cumsum_i32: memset failed"); return GS_ERR_LAUNCH; }
+    return GS_OK;
+  }
+  GS_REQUIRE(in && scratch && scratch_bytes >= gs_cumsum_scratch_bytes(n), GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_full_cumsum_i32: scratch %lld < %lld", (long long)scratch_bytes, (long long)gs_cumsum_scratch_bytes(n));
+  const int nb = int(gs_div_up(n, SCAN_BLOCK));
+  int* sums = static_cast<int*>(scratch);
+  hipLaunchKernelGGL(scan_block_sums, dim3(nb), dim3(256), 0, s, n, in, sums);
+  hipLaunchKernelGGL(scan_sums, dim3(1), dim3(1024), 0, s, nb, sums);
+  hipLaunchKernelGGL(scan_apply, dim3(nb), dim3(256), 0, s, n, in, sums, out);
+  GS_CHECK_LAUNCH("gs_full_cumsum_i32");
+  return GS_OK;
+}
+
+extern "C" int gs_tile_emit_keys(int64_t v, const float* points, const float* depth, const int32_t* offsets,
+                                 int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
+                                 uint64_t* keys, int32_t* values, void* stream) {
+  MapArgs a;
+  if (int rc = fill_args(a, v, points, depth, width, height, cfg, use_depth16)) return rc;
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(points && depth && offsets && keys && values, GS_ERR_INVALID_ARGUMENT, "gs_tile_emit_keys: NULL buffer");
+  hipLaunchKernelGGL(tile_emit_keys_kernel, dim3(unsigned(gs_div_up(v, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), a, offsets, keys, values);
+  GS_CHECK_LAUNCH("gs_tile_emit_keys");
+  return GS_OK;
+}
+
+extern "C" int gs_find_ranges(int64_t k, const uint64_t* sorted_keys, int32_t use_depth16, int64_t num_tiles,
+                              int32_t* tile_ranges, void* stream) {
+  GS_REQUIRE(tile_ranges && num_tiles > 0, GS_ERR_INVALID_ARGUMENT, "gs_find_ranges: bad arguments");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(tile_ranges, 0, size_t(num_tiles) * 8, s) != hipSuccess) {
+    gs_set_error("gs_find_ranges: memset failed");
+    return GS_ERR_LAUNCH;
+  }
+  if (k == 0) return GS_OK;
+  GS_REQUIRE(sorted_keys, GS_ERR_INVALID_ARGUMENT, "gs_find_ranges: keys is NULL");
+  hipLaunchKernelGGL(find_ranges_kernel, dim3(unsigned(gs_div_up(k, 256))), dim3(256), 0, s, k, sorted_keys,
+                     use_depth16 ? 16 : 32, tile_ranges);
+  GS_CHECK_LAUNCH("gs_find_ranges");
+  return GS_OK;
+}

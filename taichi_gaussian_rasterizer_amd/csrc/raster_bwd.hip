@@ -1,0 +1,372 @@
+// raster_bwd.hip -- gradient backward of the alpha-blend (reference rasterizer/backward.py:53-228,
+// pdf gradients taichi_lib/generic.py:321-336 / :371-404).
+//
+// Same wave-per-16x16-region layout, LDS staging and scalar sub-block masks as raster_fwd.hip.
+// What is specific to the backward:
+//   * Front-to-back re-traversal with the FINAL image as the "remaining colour"
+//     (backward.py:110,177-180).  The remaining colour only ever appears dotted with the pixel's
+//     upstream gradient, so each pixel carries ONE scalar R = sum_c rem_c * g_c instead of F
+//     channels:  R -= w * (f . g);  dL/dalpha = T (f . g) - R / (1 - alpha).
+//   * Lean kernel: the pdf gradients are linear in a few per-pixel moments, so each lane
+//     accumulates 9 sums (G, G tx, G ty, G tx^2, G ty^2, G tx dx, G tx dy, G ty dx, G ty dy with
+//     G = p * dL/dalpha) + F feature sums over its <= 4 pixels; the 7 splat gradients are formed
+//     from the wave totals once per splat, 64 splats at a time (one lane per splat).
+//   * Wave reduction by fused v_add_f32_dpp (row_ror 8/4/2/1, row_bcast 15/31): a workgroup is
+//     exactly one wave64, so the whole-tile reduction needs no LDS atomics and no barrier
+//     (the reference: warp shuffle -> shared atomic -> global atomic, concurrent.py:81-85).
+//   * Flush: one 64-byte-aligned row per Gaussian in grad_rows; a wave atomic instruction
+//     covers 4 splats x 16 contiguous floats (four 64-B memory-side atomic requests) instead of 64
+//     scattered dwords -- the difference between ~1.3 TB/s and ~0.08 TB/s of atomic bytes on
+//     MI355X (MI355X_MICROARCH.md, Global float atomics).
+//
+// Roofline: algorithmic HBM bytes 8T + K(4+28+4F) + 8PF + 4(7+F)K; VALU-bound.
+
+#include "gs_common.h"
+
+namespace {
+
+struct BwdArgs {
+  const float* points;
+  const float* features;
+  const int2* ranges;
+  const int* o2p;
+  const float* image;
+  const float* grad_image;
+  float* grad_rows;
+  int W, H, F;
+  int row_floats;
+  int tiles_wide;
+  int tile_size;
+  int sub;
+  int num_items;
+  float cmax, thr, sat;
+  int aa, heur;
+};
+
+__device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, float& ds_dx, float& ds_dsig) {
+  // taichi_lib/generic.py:360-369
+  const float z = x * inv_sigma;
+  s = gs_rcp_fast(1.0f + gs_exp2_fast((-1.6f * z - 0.07f * z * z * z) * 1.44269504088896341f));
+  const float d = (1.6f + 0.21f * z * z) * s * (1.0f - s);
+  ds_dx = d * inv_sigma;
+  ds_dsig = ds_dx * -z;
+}
+
+template <int NB, int FP, bool FULL>
+__global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
+  const int item = gs_xcd_remap(blockIdx.x, a.num_items);
+  if (item < 0) return;
+  const int lane = threadIdx.x;
+  const int per_tile = a.sub * a.sub;
+  const int tile = item / per_tile, quad = item - tile * per_tile;
+  const int region = NB == 1 ? 8 : 16;
+  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub) * region;
+  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub) * region;
+  if (x0 >= a.W || y0 >= a.H) return;
+
+  constexpr int NS = 9;                   // lean: 9 moment sums; full: 7 gradients + 2 heuristics
+  constexpr int NACC = NS + FP;           // values reduced per splat
+  constexpr int ROW = ((9 + FP + 15) / 16) * 16;
+
+  // One LDS arena per wave.  The staged records (geo, feat) and the per-splat totals (acc) are dead
+  // by the time the gradient rows (out) are written, so `out` aliases them: ~7.4 KB per wave
+  // instead of ~11.5 KB, i.e. 21 instead of 13 resident waves per CU.
+  constexpr int GEO_F = 64 * 12, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
+  constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
+  constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
+  __shared__ __attribute__((aligned(16))) float smem[ARENA_F];
+  __shared__ int s_idx[64];
+  float4(*s_geo)[3] = reinterpret_cast<float4(*)[3]>(smem);
+  float(*s_feat)[FP] = reinterpret_cast<float(*)[FP]>(smem + GEO_F);
+  float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + GEO_F + FEAT_F);
+  float(*s_out)[OUT_STRIDE] = reinterpret_cast<float(*)[OUT_STRIDE]>(smem);
+
+  const int lx = lane & 7, ly = lane >> 3;
+  float Xf[NB], Yf[NB], Wt[NB], R[NB], gpix[NB][FP];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
+    const bool inb = X < a.W && Y < a.H;
+    Xf[b] = float(X) + 0.5f;
+    Yf[b] = float(Y) + 0.5f;
+    Wt[b] = inb ? 0.0f : 1.0f;  // backward.py:99-112: out-of-image pixels start saturated
+    R[b] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < FP; ++c) gpix[b][c] = 0.0f;
+    if (inb) {
+      const int64_t pix = int64_t(Y) * a.W + X;
+#pragma unroll
+      for (int c = 0; c < FP; ++c)
+        if (c < a.F) {
+          gpix[b][c] = a.grad_image[pix * a.F + c];
+          R[b] += a.image[pix * a.F + c] * gpix[b][c];
+        }
+    }
+  }
+
+  const int2 range = a.ranges[tile];
+
+  for (int g0 = range.x; g0 < range.y; g0 += 64) {
+    // all pixels of the region saturated -> nothing further contributes (backward.py:116-118)
+    bool any_alive = false;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) any_alive |= Wt[b] < a.sat;
+    if (__ballot(any_alive) == 0ull) break;
+
+    const int cnt = min(64, range.y - g0);
+    float ax = 0, ay = 0, isx = 0, isy = 0, al = 0;
+    int idx = 0;
+    if (lane < cnt) {
+      idx = a.o2p[g0 + lane];
+      const float* p = a.points + int64_t(idx) * 7;
+      const float mx = p[0], my = p[1];
+      ax = p[2]; ay = p[3];
+      isx = 1.0f / p[4]; isy = 1.0f / p[5];
+      al = p[6];
+      const float Ax = ax * isx, Ay = ay * isx, Bx = -ay * isy, By = ax * isy;
+      int mask = 0;
+      if (FULL && a.aa) {
+        mask = (1 << NB) - 1;
+      } else if (al > a.thr) {
+        // alpha*exp(-0.5 (tx^2+ty^2)) > thr  needs  tx^2+ty^2 < 2 ln(alpha/thr)
+        const float r = sqrtf(2.0f * __logf(al / a.thr)) * 1.001f + 0.01f;
+        const float et = 3.5f * (fabsf(Ax) + fabsf(Ay)) + r, eb = 3.5f * (fabsf(Bx) + fabsf(By)) + r;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float cx = float(x0 + (b & 1) * 8) + 4.0f - mx, cy = float(y0 + (b >> 1) * 8) + 4.0f - my;
+          if (fabsf(cx * Ax + cy * Ay) <= et && fabsf(cx * Bx + cy * By) <= eb) mask |= 1 << b;
+        }
+      }
+      s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+      s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
+      s_geo[lane][2] = make_float4(ax, ay, isx, isy);
+      s_idx[lane] = idx;
+      const float* f = a.features + int64_t(idx) * a.F;
+#pragma unroll
+      for (int c = 0; c < FP; ++c) s_feat[lane][c] = c < a.F ? f[c] : 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < NACC; ++c) s_acc[lane][c] = 0.0f;
+    __syncthreads();
+
+    for (int j = 0; j < cnt; ++j) {
+      const float4 g0v = s_geo[j][0], g1v = s_geo[j][1];
+      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
+      if (mask == 0) continue;
+      float4 g2v = make_float4(0, 0, 0, 0);
+      if (FULL) g2v = s_geo[j][2];
+      float feat[FP];
+#pragma unroll
+      for (int c = 0; c < FP; ++c) feat[c] = s_feat[j][c];
+
+      float S[NS], gf[FP];
+#pragma unroll
+      for (int c = 0; c < NS; ++c) S[c] = 0.0f;
+#pragma unroll
+      for (int c = 0; c < FP; ++c) gf[c] = 0.0f;
+      bool has_grad = false;
+
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!(mask & (1 << b))) continue;  // scalar branch
+        const float dx = Xf[b] - g0v.x, dy = Yf[b] - g0v.y;
+        float p, tx = 0, ty = 0;
+        float dmx = 0, dmy = 0, dax = 0, day = 0, dsx = 0, dsy = 0;
+        if (FULL && a.aa) {
+          // taichi_lib/generic.py:371-404
+          const float axv = g2v.x, ayv = g2v.y, sxv = 1.0f / g2v.z, syv = 1.0f / g2v.w;
+          const float ux = dx * axv + dy * ayv, uy = dy * axv - dx * ayv;
+          float Sx1, dSx1, dSx1s, Sx2, dSx2, dSx2s, Sy1, dSy1, dSy1s, Sy2, dSy2, dSy2s;
+          s_sig_grad(ux + 0.5f, g2v.z, Sx1, dSx1, dSx1s);
+          s_sig_grad(ux - 0.5f, g2v.z, Sx2, dSx2, dSx2s);
+          s_sig_grad(uy + 0.5f, g2v.w, Sy1, dSy1, dSy1s);
+          s_sig_grad(uy - 0.5f, g2v.w, Sy2, dSy2, dSy2s);
+          const float tau = 6.28318530717958648f;
+          const float ix = sxv * (Sx1 - Sx2), iy = syv * (Sy1 - Sy2);
+          p = tau * ix * iy;
+          const float dSx = iy * sxv * (dSx1 - dSx2), dSy = ix * syv * (dSy1 - dSy2);
+          dmx = tau * (dSx * -axv + dSy * ayv);
+          dmy = tau * (dSx * -ayv + dSy * -axv);
+          dsx = tau * iy * (Sx1 - Sx2 + (dSx1s - dSx2s) * sxv);
+          dsy = tau * ix * (Sy1 - Sy2 + (dSy1s - dSy2s) * syv);
+          dax = tau * (dSx * dx + dSy * dy);
+          day = tau * (dSx * dy + dSy * -dx);
+        } else {
+          tx = dx * g0v.z + dy * g0v.w;
+          ty = dx * g1v.x + dy * g1v.y;
+          p = gs_exp2_fast(-0.72134752044448170f * (tx * tx + ty * ty));
+          if (FULL) {
+            // taichi_lib/generic.py:321-336
+            const float txs = tx * g2v.z, tys = ty * g2v.w;
+            dsx = tx * tx * p * g2v.z;
+            dsy = ty * ty * p * g2v.w;
+            dax = p * (txs * -dx + tys * -dy);
+            day = p * (txs * -dy + tys * dx);
+            dmx = p * (txs * g2v.x - tys * g2v.y);
+            dmy = p * (txs * g2v.y + tys * g2v.x);
+          }
+        }
+        const float alpha_raw = g1v.z * p;
+        const bool hit = alpha_raw > a.thr && Wt[b] < a.sat;  // backward.py:160,166
+        if (__ballot(hit) == 0ull) continue;
+        has_grad |= hit;
+        const float alc = fminf(alpha_raw, a.cmax);          // :169
+        const float T = 1.0f - Wt[b];
+        const float w = hit ? alc * T : 0.0f;
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) dot += feat[c] * gpix[b][c];
+        Wt[b] += w;
+        R[b] -= w * dot;
+        // dL/dalpha = sum_c (f_c T - rem_c / (1 - alpha)) g_c   (:180-182)
+        const float alpha_grad = hit ? (T * dot - R[b] * gs_rcp_fast(1.0f - alc)) : 0.0f;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) gf[c] += w * gpix[b][c];  // :201
+        if (FULL) {
+          const float aag = g1v.z * alpha_grad;  // :184
+          S[0] += aag * dmx; S[1] += aag * dmy;
+          S[2] += aag * dax; S[3] += aag * day;
+          S[4] += aag * dsx; S[5] += aag * dsy;
+          S[6] += p * alpha_grad;
+          S[7] += aag * aag;                                  // :194-198
+          S[8] += fabsf(aag * dmx) + fabsf(aag * dmy);
+        } else {
+          const float G = p * alpha_grad;
+          const float Gtx = G * tx, Gty = G * ty;
+          S[0] += G;
+          S[1] += Gtx; S[2] += Gty;
+          S[3] += Gtx * tx; S[4] += Gty * ty;
+          S[5] += Gtx * dx; S[6] += Gtx * dy;
+          S[7] += Gty * dx; S[8] += Gty * dy;
+        }
+      }
+
+      // reduce over the wave only if some pixel took a gradient (backward.py:204)
+      if (__ballot(has_grad) != 0ull) {
+        float tot[NACC];
+#pragma unroll
+        for (int c = 0; c < NS; ++c) tot[c] = gs_wave_sum_to_lane63(S[c]);
+#pragma unroll
+        for (int c = 0; c < FP; ++c) tot[NS + c] = gs_wave_sum_to_lane63(gf[c]);
+        if (lane == 63) {
+#pragma unroll
+          for (int c = 0; c < NACC; ++c) s_acc[j][c] = tot[c];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- per-splat epilogue: lane j turns splat j's totals into its gradient row
+    {
+      float row[ROW];
+#pragma unroll
+      for (int c = 0; c < ROW; ++c) row[c] = 0.0f;
+      if (lane < cnt) {
+        float t[NACC];
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) t[c] = s_acc[lane][c];
+        if (FULL) {
+#pragma unroll
+          for (int c = 0; c < 7; ++c) row[c] = t[c];
+          if (a.heur) { row[7 + FP] = t[7]; row[8 + FP] = t[8]; }
+        } else {
+          row[0] = al * (t[1] * isx * ax - t[2] * isy * ay);
+          row[1] = al * (t[1] * isx * ay + t[2] * isy * ax);
+          row[2] = -al * (isx * t[5] + isy * t[8]);
+          row[3] = al * (isy * t[7] - isx * t[6]);
+          row[4] = al * t[3] * isx;
+          row[5] = al * t[4] * isy;
+          row[6] = t[0];
+        }
+#pragma unroll
+        for (int c = 0; c < FP; ++c) row[7 + c] = t[NS + c];
+      }
+      __syncthreads();  // `out` aliases the totals just read
+#pragma unroll
+      for (int c = 0; c < ROW; ++c) s_out[lane][c] = row[c];
+    }
+    __syncthreads();
+    // ---- flush: 64/ROW splats x ROW contiguous floats per wave atomic instruction
+    for (int e = lane; e < cnt * ROW; e += 64) {
+      const int jj = e / ROW, comp = e - jj * ROW;
+      const float val = s_out[jj][comp];
+      // heuristics live at [7+F, 9+F) of the caller's row; the kernel's padded slot is 7+FP
+      int dst = comp;
+      if (comp >= 7 + FP) dst = comp - FP + a.F;
+      else if (comp >= 7 + a.F) continue;
+      if (val != 0.0f) atomicAdd(a.grad_rows + int64_t(s_idx[jj]) * a.row_floats + dst, val);
+    }
+    __syncthreads();
+  }
+}
+
+template <int NB, bool FULL>
+int launch_fp(const BwdArgs& a, hipStream_t s) {
+  const int grid = 8 * int(gs_div_up(a.num_items, 8));
+  if (a.F <= 3) hipLaunchKernelGGL((raster_bwd_kernel<NB, 3, FULL>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 5) hipLaunchKernelGGL((raster_bwd_kernel<NB, 5, FULL>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 8) hipLaunchKernelGGL((raster_bwd_kernel<NB, 8, FULL>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((raster_bwd_kernel<NB, 32, FULL>), dim3(grid), dim3(64), 0, s, a);
+  GS_CHECK_LAUNCH("gs_raster_bwd");
+  return GS_OK;
+}
+
+__global__ void unpack_kernel(int64_t v, int F, int row_floats, const float* rows, float* gp, float* gf, float* heur) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int per = 9 + F;
+  if (i >= v * per) return;
+  const int64_t r = i / per;
+  const int c = int(i - r * per);
+  const float val = rows[r * row_floats + c];
+  if (c < 7) { if (gp) gp[r * 7 + c] = val; }
+  else if (c < 7 + F) { if (gf) gf[r * F + (c - 7)] = val; }
+  else if (heur) heur[r * 2 + (c - 7 - F)] = val;
+}
+
+}  // namespace
+
+extern "C" int32_t gs_grad_row_floats(int32_t num_features) { return int32_t(gs_align_up(9 + num_features, 16)); }
+
+extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
+                             const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
+                             int32_t height, const GsRasterConfig* cfg, const float* image, const float* grad_image,
+                             float* grad_rows, void* stream) {
+  if (int rc = gs_check_cfg(cfg)) return rc;
+  GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_bwd: image size %dx%d", width, height);
+  GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
+             "gs_raster_bwd: feature width %d not in [1,%d]", num_features, GS_MAX_FEATURES);
+  GS_REQUIRE(image && grad_image && tile_ranges, GS_ERR_INVALID_ARGUMENT, "gs_raster_bwd: NULL image or ranges");
+  GS_REQUIRE(cfg->use_alpha_blending, GS_ERR_UNSUPPORTED,
+             "gs_raster_bwd: no gradient is defined without alpha blending (reference tests/test_rasterizer.py:92-101)");
+  if (k == 0 || v == 0) return GS_OK;
+  GS_REQUIRE(points && features && overlap_to_point && grad_rows, GS_ERR_INVALID_ARGUMENT,
+             "gs_raster_bwd: NULL input");
+  const int ts = cfg->tile_size;
+  BwdArgs a;
+  a.points = points; a.features = features; a.ranges = reinterpret_cast<const int2*>(tile_ranges);
+  a.o2p = overlap_to_point; a.image = image; a.grad_image = grad_image; a.grad_rows = grad_rows;
+  a.W = width; a.H = height; a.F = num_features;
+  a.row_floats = gs_grad_row_floats(num_features);
+  a.tiles_wide = int(gs_div_up(width, ts));
+  a.tile_size = ts;
+  a.sub = ts == 32 ? 2 : 1;
+  a.num_items = a.tiles_wide * int(gs_div_up(height, ts)) * a.sub * a.sub;
+  a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
+  a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool full = a.aa || a.heur;
+  if (ts == 8) return full ? launch_fp<1, true>(a, s) : launch_fp<1, false>(a, s);
+  return full ? launch_fp<4, true>(a, s) : launch_fp<4, false>(a, s);
+}
+
+extern "C" int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
+                                    float* grad_features, float* point_heuristic, void* stream) {
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(grad_rows, GS_ERR_INVALID_ARGUMENT, "gs_raster_bwd_unpack: grad_rows is NULL");
+  const int64_t total = v * (9 + num_features);
+  hipLaunchKernelGGL(unpack_kernel, dim3(unsigned(gs_div_up(total, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), v, num_features, gs_grad_row_floats(num_features), grad_rows,
+                     grad_points, grad_features, point_heuristic);
+  GS_CHECK_LAUNCH("gs_raster_bwd_unpack");
+  return GS_OK;
+}

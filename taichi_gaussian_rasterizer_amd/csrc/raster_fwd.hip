@@ -1,0 +1,238 @@
+// raster_fwd.hip -- front-to-back alpha-blend forward (reference rasterizer/forward.py:25-137).
+//
+// MI355X mapping (not the reference's 256-thread / 1-pixel-per-thread block):
+//   * ONE wave64 per 16x16 pixel region (a whole tile at tile_size 16, a quadrant at 32; an 8x8
+//     tile is one sub-block).  Lane l owns pixel (l&7, l>>3) of each of the region's four 8x8
+//     sub-blocks, i.e. 4 pixels per lane.  A workgroup is a single wave, so there are no
+//     s_barriers and no cross-wave LDS traffic.
+//   * The tile's splat list is staged 64 at a time: lane j gathers splat j (28 B + 4F B row,
+//     index from overlap_to_point), pre-multiplies the ellipse frame (axis/sigma scaled so that
+//     alpha = a * exp2(-(tx^2+ty^2))) and writes one LDS record.  The blend loop then reads each
+//     record with wave-uniform (broadcast) ds_read_b128s.
+//   * While staging, each lane also tests its splat against the four 8x8 sub-blocks in the
+//     ellipse frame (conservative, with a margin that keeps alpha strictly below the threshold
+//     outside) and stores a 4-bit mask; the blend loop branches on it with SCALAR branches, so
+//     sub-blocks a splat cannot touch cost nothing and nothing diverges.  Results are identical
+//     to evaluating every pixel: a skipped pixel would have failed `alpha > alpha_threshold`.
+//   * Launch: grid = regions, XCD-aware remap so that neighbouring tiles (which gather the same
+//     splat rows) share an L2.
+//
+// Roofline: algorithmic HBM bytes K*(4 + 28 + 4F) + 16T + 4P(F+1); the kernel is
+// VALU-bound (about 20 VALU + 1 v_exp_f32 per evaluated pixel-splat pair).
+
+#include "gs_common.h"
+
+namespace {
+
+struct FwdArgs {
+  const float* points;
+  const float* features;
+  const int2* ranges;
+  const int* o2p;
+  float* image;
+  float* alpha;
+  float* visibility;
+  int W, H, F;
+  int tiles_wide;
+  int tile_size;
+  int sub;        // 16x16 regions per tile side (1, or 2 at tile_size 32)
+  int num_items;  // tiles * sub * sub
+  float cmax, thr, sat_level;
+  int blend, vis, aa;
+};
+
+__device__ __forceinline__ float s_sig(float x, float inv_sigma) {
+  const float z = x * inv_sigma;
+  const float e = -1.6f * z - 0.07f * z * z * z;
+  return gs_rcp_fast(1.0f + gs_exp2_fast(e * 1.44269504088896341f));
+}
+
+// NB: 8x8 sub-blocks per wave (1 or 4).  FP: padded feature width.  FULL: runtime switches for
+// quantile mode / visibility / antialias (the common blend-only case gets its own lean kernel).
+template <int NB, int FP, bool FULL>
+__global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
+  const int item = gs_xcd_remap(blockIdx.x, a.num_items);
+  if (item < 0) return;
+  const int lane = threadIdx.x;
+  const int per_tile = a.sub * a.sub;
+  const int tile = item / per_tile, quad = item - tile * per_tile;
+  const int region = NB == 1 ? 8 : 16;
+  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub) * region;
+  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub) * region;
+  if (x0 >= a.W || y0 >= a.H) return;
+
+  __shared__ float4 s_geo[64][FULL ? 3 : 2];
+  __shared__ float s_feat[64][FP];
+  __shared__ float s_vis[FULL ? 64 : 1];
+  __shared__ int s_idx[FULL ? 64 : 1];
+
+  const int lx = lane & 7, ly = lane >> 3;
+  float Xf[NB], Yf[NB], Wt[NB], acc[NB][FP];
+  bool inb[NB], done[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
+    inb[b] = X < a.W && Y < a.H;
+    Xf[b] = float(X) + 0.5f;
+    Yf[b] = float(Y) + 0.5f;
+    Wt[b] = inb[b] ? 0.0f : 1.0f;  // forward.py:53-54
+    done[b] = false;
+#pragma unroll
+    for (int c = 0; c < FP; ++c) acc[b][c] = 0.0f;
+  }
+
+  const int2 range = a.ranges[tile];
+  const float k_exp = 0.84932180028801904f;  // sqrt(0.5 * log2(e)): exp(-0.5 t^2) = exp2(-(k t)^2)
+
+  for (int g0 = range.x; g0 < range.y; g0 += 64) {
+    const int cnt = min(64, range.y - g0);
+    // ---- stage up to 64 splats: lane j <- splat g0 + j
+    if (lane < cnt) {
+      const int idx = a.o2p[g0 + lane];
+      const float* p = a.points + int64_t(idx) * 7;
+      const float mx = p[0], my = p[1], ax = p[2], ay = p[3], sx = p[4], sy = p[5], al = p[6];
+      const float isx = 1.0f / sx, isy = 1.0f / sy;
+      const float Ax = ax * isx * k_exp, Ay = ay * isx * k_exp;
+      const float Bx = -ay * isy * k_exp, By = ax * isy * k_exp;
+      // conservative sub-block mask: alpha*exp2(-(tx^2+ty^2)) > thr needs tx^2+ty^2 < log2(alpha/thr)
+      int mask = 0;
+      const bool use_mask = !(FULL && a.aa);
+      if (!use_mask) {
+        mask = (1 << NB) - 1;
+      } else if (al > a.thr) {
+        const float r = sqrtf(__log2f(al / a.thr)) * 1.001f + 0.01f;
+        const float et = 3.5f * (fabsf(Ax) + fabsf(Ay)) + r, eb = 3.5f * (fabsf(Bx) + fabsf(By)) + r;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const float cx = float(x0 + (b & 1) * 8) + 4.0f - mx, cy = float(y0 + (b >> 1) * 8) + 4.0f - my;
+          const float tc = cx * Ax + cy * Ay, bc = cx * Bx + cy * By;
+          if (fabsf(tc) <= et && fabsf(bc) <= eb) mask |= 1 << b;
+        }
+      }
+      s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+      s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
+      if (FULL) {
+        s_geo[lane][2] = make_float4(ax, ay, isx, isy);
+        s_vis[lane] = 0.0f;
+        s_idx[lane] = idx;
+      }
+      const float* f = a.features + int64_t(idx) * a.F;
+#pragma unroll
+      for (int c = 0; c < FP; ++c) s_feat[lane][c] = c < a.F ? f[c] : 0.0f;
+    }
+    __syncthreads();  // single-wave workgroup: compiles to a wait on the LDS writes, no s_barrier
+
+    // ---- blend
+    for (int j = 0; j < cnt; ++j) {
+      const float4 g0v = s_geo[j][0], g1v = s_geo[j][1];
+      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
+      if (mask == 0) continue;
+      float feat[FP];
+#pragma unroll
+      for (int c = 0; c < FP; ++c) feat[c] = s_feat[j][c];
+      float4 g2v = make_float4(0, 0, 0, 0);
+      if (FULL) g2v = s_geo[j][2];
+      float vis_sum = 0.0f;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        if (!(mask & (1 << b))) continue;  // scalar branch
+        const float dx = Xf[b] - g0v.x, dy = Yf[b] - g0v.y;
+        float p;
+        if (FULL && a.aa) {
+          // taichi_lib/generic.py:347-357
+          const float tx = dx * g2v.x + dy * g2v.y, ty = dy * g2v.x - dx * g2v.y;
+          const float sxv = 1.0f / g2v.z, syv = 1.0f / g2v.w;
+          p = 6.28318530717958648f * sxv * (s_sig(tx + 0.5f, g2v.z) - s_sig(tx - 0.5f, g2v.z)) * syv *
+              (s_sig(ty + 0.5f, g2v.w) - s_sig(ty - 0.5f, g2v.w));
+        } else {
+          const float tx = dx * g0v.z + dy * g0v.w, ty = dx * g1v.x + dy * g1v.y;
+          p = gs_exp2_fast(-(tx * tx + ty * ty));
+        }
+        const float al = fminf(g1v.z * p, a.cmax);  // forward.py:98-99
+        bool hit = al > a.thr;
+        if (FULL) hit = hit && !done[b];
+        const float w = hit ? al * (1.0f - Wt[b]) : 0.0f;
+        Wt[b] += w;
+        if (!FULL || a.blend) {
+#pragma unroll
+          for (int c = 0; c < FP; ++c) acc[b][c] += feat[c] * w;
+        } else if (hit) {  // forward.py:109-114 quantile mode: first splat that reaches the level
+          if (Wt[b] >= a.sat_level) {
+#pragma unroll
+            for (int c = 0; c < FP; ++c) acc[b][c] = feat[c];
+            done[b] = true;
+          }
+        }
+        vis_sum += w;
+      }
+      if (FULL && a.vis) {
+        // forward.py:116-128: per-splat visibility = sum of blend weights over the tile's pixels
+        if (__builtin_amdgcn_readfirstlane(__ballot(vis_sum != 0.0f) != 0ull)) {
+          const float tot = gs_wave_sum_to_lane63(vis_sum);
+          if (lane == 63) s_vis[j] += tot;
+        }
+      }
+    }
+    if (FULL && a.vis) {
+      __syncthreads();
+      if (lane < cnt && s_vis[lane] != 0.0f) atomicAdd(a.visibility + s_idx[lane], s_vis[lane]);
+    }
+    __syncthreads();  // records are overwritten by the next group
+  }
+
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    if (!inb[b]) continue;
+    const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
+    const int64_t pix = int64_t(Y) * a.W + X;
+    float* out = a.image + pix * a.F;
+#pragma unroll
+    for (int c = 0; c < FP; ++c)
+      if (c < a.F) out[c] = acc[b][c];
+    a.alpha[pix] = (!FULL || a.blend) ? Wt[b] : (Wt[b] > 0.0f ? 1.0f : 0.0f);  // forward.py:134-137
+  }
+}
+
+template <int NB, bool FULL>
+int launch_fp(const FwdArgs& a, hipStream_t s) {
+  const int grid = 8 * int(gs_div_up(a.num_items, 8));
+  if (a.F <= 3) hipLaunchKernelGGL((raster_fwd_kernel<NB, 3, FULL>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 5) hipLaunchKernelGGL((raster_fwd_kernel<NB, 5, FULL>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 8) hipLaunchKernelGGL((raster_fwd_kernel<NB, 8, FULL>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((raster_fwd_kernel<NB, 32, FULL>), dim3(grid), dim3(64), 0, s, a);
+  GS_CHECK_LAUNCH("gs_raster_fwd");
+  return GS_OK;
+}
+
+}  // namespace
+
+extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
+                             const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
+                             int32_t height, const GsRasterConfig* cfg, float* image, float* alpha,
+                             float* visibility, void* stream) {
+  if (int rc = gs_check_cfg(cfg)) return rc;
+  GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_fwd: image size %dx%d", width, height);
+  GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
+             "gs_raster_fwd: feature width %d not in [1,%d]", num_features, GS_MAX_FEATURES);
+  GS_REQUIRE(image && alpha && tile_ranges, GS_ERR_INVALID_ARGUMENT, "gs_raster_fwd: NULL output or ranges");
+  GS_REQUIRE(k == 0 || (points && features && overlap_to_point), GS_ERR_INVALID_ARGUMENT,
+             "gs_raster_fwd: NULL input with %lld overlaps", (long long)k);
+  const bool vis = cfg->compute_visibility || cfg->compute_point_heuristic;
+  GS_REQUIRE(!vis || visibility || v == 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_fwd: visibility buffer is NULL");
+  const int ts = cfg->tile_size;
+  FwdArgs a;
+  a.points = points; a.features = features; a.ranges = reinterpret_cast<const int2*>(tile_ranges);
+  a.o2p = overlap_to_point; a.image = image; a.alpha = alpha; a.visibility = visibility;
+  a.W = width; a.H = height; a.F = num_features;
+  a.tiles_wide = int(gs_div_up(width, ts));
+  a.tile_size = ts;
+  a.sub = ts == 32 ? 2 : 1;
+  a.num_items = a.tiles_wide * int(gs_div_up(height, ts)) * a.sub * a.sub;
+  a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
+  a.sat_level = 1.0f - cfg->saturate_threshold;
+  a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool full = !a.blend || a.vis || a.aa;
+  if (ts == 8) return full ? launch_fp<1, true>(a, s) : launch_fp<1, false>(a, s);
+  return full ? launch_fp<4, true>(a, s) : launch_fp<4, false>(a, s);
+}

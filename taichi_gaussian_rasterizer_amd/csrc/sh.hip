@@ -1,0 +1,216 @@
+// sh.hip -- view-dependent colour from real spherical harmonics, degree 0..3, and its adjoint.
+// Reference: spherical_harmonics.py:38-106 (rsh_cart_0..3), :118-134 (evaluate_sh_at_kernel),
+// :154-161 (backward by Taichi autodiff).  out[c] = clamp(sum_d Y_d(dir) * sh[idx,c,d] + 0.5, 0, 1),
+// dir = normalize(p[idx] - camera).
+//
+// HBM-bound: forward reads 4CD + 12 + 8 bytes and writes 4C per visible Gaussian; backward writes
+// the dense (N,C,D) gradient (zero rows for culled Gaussians).  One lane per visible Gaussian; the
+// coefficient row (192 B at degree 3, C = 3) is read with 16-byte loads when its size allows.
+
+#include "gs_common.h"
+
+namespace {
+
+constexpr float C1 = 0.48860251190292f, C2 = 1.09254843059208f, C3 = 0.94617469575756f, C4 = 0.31539156525252f,
+                C5 = 0.54627421529604f, C6 = 0.590043589926644f, C7 = 2.89061144264055f, C8 = 0.304697199642977f,
+                C9 = 1.24392110863372f, C10 = 0.497568443453487f, C11 = 1.44530572132028f;
+
+template <int DEG>
+__device__ __forceinline__ void rsh(float x, float y, float z, float* Y) {
+  Y[0] = 0.282094791773878f;
+  if (DEG >= 1) { Y[1] = -C1 * y; Y[2] = C1 * z; Y[3] = -C1 * x; }
+  if (DEG >= 2) {
+    Y[4] = C2 * (x * y); Y[5] = -C2 * (y * z); Y[6] = C3 * (z * z) - C4; Y[7] = -C2 * (x * z);
+    Y[8] = C5 * (x * x) - C5 * (y * y);
+  }
+  if (DEG >= 3) {
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    Y[9] = -C6 * y * (3.0f * x2 - y2);
+    Y[10] = C7 * (x * y) * z;
+    Y[11] = C8 * y * (1.5f - 7.5f * z2);
+    Y[12] = C9 * z * (1.5f * z2 - 0.5f) - C10 * z;
+    Y[13] = C8 * x * (1.5f - 7.5f * z2);
+    Y[14] = C11 * z * (x2 - y2);
+    Y[15] = -C6 * x * (x2 - 3.0f * y2);
+  }
+}
+
+// g_dir = sum_d w[d] * dY_d/d(x,y,z)
+template <int DEG>
+__device__ __forceinline__ void rsh_grad(float x, float y, float z, const float* w, float* g) {
+  g[0] = g[1] = g[2] = 0.0f;
+  if (DEG >= 1) { g[1] += -C1 * w[1]; g[2] += C1 * w[2]; g[0] += -C1 * w[3]; }
+  if (DEG >= 2) {
+    g[0] += C2 * y * w[4];            g[1] += C2 * x * w[4];
+    g[1] += -C2 * z * w[5];           g[2] += -C2 * y * w[5];
+    g[2] += 2.0f * C3 * z * w[6];
+    g[0] += -C2 * z * w[7];           g[2] += -C2 * x * w[7];
+    g[0] += 2.0f * C5 * x * w[8];     g[1] += -2.0f * C5 * y * w[8];
+  }
+  if (DEG >= 3) {
+    const float x2 = x * x, y2 = y * y, z2 = z * z;
+    g[0] += -6.0f * C6 * x * y * w[9];          g[1] += -C6 * (3.0f * x2 - 3.0f * y2) * w[9];
+    g[0] += C7 * y * z * w[10];                 g[1] += C7 * x * z * w[10];            g[2] += C7 * x * y * w[10];
+    g[1] += C8 * (1.5f - 7.5f * z2) * w[11];    g[2] += -15.0f * C8 * y * z * w[11];
+    g[2] += (C9 * (4.5f * z2 - 0.5f) - C10) * w[12];
+    g[0] += C8 * (1.5f - 7.5f * z2) * w[13];    g[2] += -15.0f * C8 * x * z * w[13];
+    g[0] += 2.0f * C11 * x * z * w[14];         g[1] += -2.0f * C11 * y * z * w[14];   g[2] += C11 * (x2 - y2) * w[14];
+    g[0] += -C6 * (3.0f * x2 - 3.0f * y2) * w[15];  g[1] += 6.0f * C6 * x * y * w[15];
+  }
+}
+
+template <int D>
+__device__ __forceinline__ void load_row(const float* row, float* out) {
+  if ((D & 3) == 0) {  // rows of 16-byte multiples (degree 1 and 3) are 16-byte aligned for any C
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+#pragma unroll
+    for (int k = 0; k < D / 4; ++k) {
+      const float4 t = r4[k];
+      out[4 * k] = t.x; out[4 * k + 1] = t.y; out[4 * k + 2] = t.z; out[4 * k + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < D; ++k) out[k] = row[k];
+  }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, int C, const float* params, const float* positions,
+                                                     const int64_t* indexes, const float* cam, float* out) {
+  constexpr int D = (DEG + 1) * (DEG + 1);
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= v) return;
+  const int64_t idx = indexes[i];
+  const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1], dz = positions[3 * idx + 2] - cam[2];
+  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+  float Y[D];
+  rsh<DEG>(dx / nrm, dy / nrm, dz / nrm, Y);
+  for (int c = 0; c < C; ++c) {
+    float row[D];
+    load_row<D>(params + (idx * C + c) * D, row);
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) acc += Y[d] * row[d];
+    out[i * C + c] = fminf(fmaxf(acc + 0.5f, 0.0f), 1.0f);
+  }
+}
+
+template <int DEG, bool UNIQUE>
+__global__ __launch_bounds__(256) void sh_bwd_kernel(int64_t v, int C, const float* params, const float* positions,
+                                                     const int64_t* indexes, const float* cam, const float* gout,
+                                                     float* d_params, float* d_positions, float* d_cam) {
+  constexpr int D = (DEG + 1) * (DEG + 1);
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  float gd[3] = {0, 0, 0};
+  if (i < v) {
+    const int64_t idx = indexes[i];
+    const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1],
+                dz = positions[3 * idx + 2] - cam[2];
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float x = dx / nrm, y = dy / nrm, z = dz / nrm;
+    float Y[D], w[D];
+    rsh<DEG>(x, y, z, Y);
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = 0.0f;
+    for (int c = 0; c < C; ++c) {
+      float row[D];
+      load_row<D>(params + (idx * C + c) * D, row);
+      float acc = 0.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc += Y[d] * row[d];
+      const float pre = acc + 0.5f;
+      const float g = (pre >= 0.0f && pre <= 1.0f) ? gout[i * C + c] : 0.0f;  // clamp sub-gradient
+      float* drow = d_params + (idx * C + c) * D;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (UNIQUE) drow[d] = g * Y[d];
+        else if (g != 0.0f) atomicAdd(drow + d, g * Y[d]);
+        w[d] += g * row[d];
+      }
+    }
+    if (DEG >= 1 && (d_positions || d_cam)) {
+      float gdir[3];
+      rsh_grad<DEG>(x, y, z, w, gdir);
+      const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+      gd[0] = (gdir[0] - x * dot) / nrm;
+      gd[1] = (gdir[1] - y * dot) / nrm;
+      gd[2] = (gdir[2] - z * dot) / nrm;
+      if (d_positions) {
+        if (UNIQUE) { d_positions[3 * idx] = gd[0]; d_positions[3 * idx + 1] = gd[1]; d_positions[3 * idx + 2] = gd[2]; }
+        else { atomicAdd(d_positions + 3 * idx, gd[0]); atomicAdd(d_positions + 3 * idx + 1, gd[1]); atomicAdd(d_positions + 3 * idx + 2, gd[2]); }
+      }
+    }
+  }
+  if (d_cam && DEG >= 1) {
+    __shared__ float s_part[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float tot = gs_wave_sum_to_lane63(gd[k]);
+      if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6][k] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+      atomicAdd(d_cam + threadIdx.x,
+                -(s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x]));
+  }
+}
+
+}  // namespace
+
+extern "C" int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
+                         const int64_t* indexes, const float* camera_pos, float* out, void* stream) {
+  GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "gs_sh_fwd: SH degree %d not in [0,3]", degree);
+  GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "gs_sh_fwd: %d channels", channels);
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(params && positions && indexes && camera_pos && out, GS_ERR_INVALID_ARGUMENT, "gs_sh_fwd: NULL buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(unsigned(gs_div_up(v, 256))), block(256);
+  switch (degree) {
+    case 0: hipLaunchKernelGGL(sh_fwd_kernel<0>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
+    case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
+    case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
+    default: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
+  }
+  GS_CHECK_LAUNCH("gs_sh_fwd");
+  return GS_OK;
+}
+
+#define SH_BWD_LAUNCH(DEG, UNIQ)                                                                                    \
+  hipLaunchKernelGGL((sh_bwd_kernel<DEG, UNIQ>), grid, block, 0, s, v, channels, params, positions, indexes,        \
+                     camera_pos, grad_out, d_params, d_positions, d_camera_pos)
+
+extern "C" int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params,
+                         const float* positions, const int64_t* indexes, int32_t indexes_unique,
+                         const float* camera_pos, const float* grad_out, float* d_params, float* d_positions,
+                         float* d_camera_pos, void* stream) {
+  GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "gs_sh_bwd: SH degree %d not in [0,3]", degree);
+  GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "gs_sh_bwd: %d channels", channels);
+  GS_REQUIRE(n == 0 || d_params, GS_ERR_INVALID_ARGUMENT, "gs_sh_bwd: d_params is NULL");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int D = (degree + 1) * (degree + 1);
+  bool ok = true;
+  if (n > 0) ok &= hipMemsetAsync(d_params, 0, size_t(n) * channels * D * 4, s) == hipSuccess;
+  if (n > 0 && d_positions) ok &= hipMemsetAsync(d_positions, 0, size_t(n) * 12, s) == hipSuccess;
+  if (d_camera_pos) ok &= hipMemsetAsync(d_camera_pos, 0, 12, s) == hipSuccess;
+  if (!ok) { gs_set_error("gs_sh_bwd: hipMemsetAsync failed"); return GS_ERR_LAUNCH; }
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(params && positions && indexes && camera_pos && grad_out, GS_ERR_INVALID_ARGUMENT, "gs_sh_bwd: NULL buffer");
+  const dim3 grid(unsigned(gs_div_up(v, 256))), block(256);
+  if (indexes_unique) {
+    switch (degree) {
+      case 0: SH_BWD_LAUNCH(0, true); break;
+      case 1: SH_BWD_LAUNCH(1, true); break;
+      case 2: SH_BWD_LAUNCH(2, true); break;
+      default: SH_BWD_LAUNCH(3, true); break;
+    }
+  } else {
+    switch (degree) {
+      case 0: SH_BWD_LAUNCH(0, false); break;
+      case 1: SH_BWD_LAUNCH(1, false); break;
+      case 2: SH_BWD_LAUNCH(2, false); break;
+      default: SH_BWD_LAUNCH(3, false); break;
+    }
+  }
+  GS_CHECK_LAUNCH("gs_sh_bwd");
+  return GS_OK;
+}

@@ -1,0 +1,298 @@
+"""HIP path vs CPU oracle on the same seeded inputs (run with -m gpu on an MI355X).
+Integer stages (tile decisions, sort keys, order, ranges, scans) are compared bit for bit;
+floating-point stages within the tolerances stated in parity_util.py."""
+import numpy as np
+import pytest
+import torch
+
+import parity_util as pu
+from golden_util import load_cases, projection_cases, sh_cases
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+import taichi_gaussian_rasterizer_amd as gs  # noqa: E402
+from taichi_gaussian_rasterizer_amd import RasterConfig, scenes  # noqa: E402
+from taichi_gaussian_rasterizer_amd.mapper.tile_mapper import map_to_tiles_reference_stages  # noqa: E402
+from taichi_gaussian_rasterizer_amd.perspective import projection as hip_proj  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def dev(x, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(x)) if not isinstance(x, torch.Tensor) else x
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+# ------------------------------------------------------------------------------------ mapper
+MAPPER_CASES = [(0, 500, (320, 200), 16, False), (1, 2000, (257, 131), 16, False), (2, 300, (64, 64), 8, True),
+                (3, 50, (100, 40), 32, False), (4, 20000, (640, 360), 16, False), (5, 3000, (96, 96), 16, True),
+                (6, 1, (16, 16), 16, False), (7, 5000, (40, 24), 8, False)]
+
+
+@pytest.mark.parametrize("seed,n,size,tile,depth16", MAPPER_CASES)
+def test_mapper_bit_exact(seed, n, size, tile, depth16):
+    g2d, depth, _ = pu.make_2d_scene(seed, n, size, scale_factor=0.7, alpha_range=(0.001, 1.0))
+    cfg = RasterConfig(tile_size=tile)
+    o2p_ref, ranges_ref, keys_ref = orc.map_to_tiles(g2d, depth, size, orc.OracleConfig.of(cfg), depth16, return_keys=True)
+    for fn in (gs.map_to_tiles, map_to_tiles_reference_stages):
+        o2p, ranges, keys = fn(dev(g2d), dev(depth), size, cfg, use_depth16=depth16, return_keys=True)
+        torch.cuda.synchronize()
+        assert o2p.dtype == torch.int32 and ranges.dtype == torch.int32
+        assert tuple(ranges.shape) == ranges_ref.shape
+        assert (pu.to_np(ranges) == ranges_ref).all(), f"{fn.__name__}: tile ranges differ"
+        assert (pu.to_np(o2p) == o2p_ref).all(), f"{fn.__name__}: overlap order differs"
+        assert (pu.to_np(keys).view(np.uint64) == keys_ref).all(), f"{fn.__name__}: sort keys differ"
+
+
+def test_mapper_crowded_tile_uses_global_bitonic():
+    """more splats on one tile than the LDS sort holds (8192): in-place global-memory bitonic path"""
+    torch.manual_seed(0)
+    n = 9000
+    g2d = torch.cat([torch.rand(n, 2) * 14 + 1, torch.tensor([[1.0, 0.0]]).expand(n, 2), torch.rand(n, 2) + 0.5,
+                     torch.rand(n, 1) * 0.5 + 0.3], 1).float()
+    depth = torch.rand(n, 1)
+    cfg = RasterConfig()
+    o2p_ref, ranges_ref = orc.map_to_tiles(g2d, depth, (16, 16), orc.OracleConfig.of(cfg))
+    o2p, ranges = gs.map_to_tiles(dev(g2d), dev(depth), (16, 16), cfg)
+    assert (pu.to_np(ranges) == ranges_ref).all() and (pu.to_np(o2p) == o2p_ref).all()
+
+
+def test_mapper_empty_and_culled():
+    cfg = RasterConfig()
+    o2p, ranges = gs.map_to_tiles(torch.zeros((0, 7), device=DEV), torch.zeros((0, 1), device=DEV), (40, 30), cfg)
+    assert o2p.shape == (0,) and tuple(ranges.shape) == (2, 3, 2) and int(ranges.abs().sum()) == 0
+    g = torch.tensor([[20., 15., 1., 0., 3., 3., 0.001], [-500., -500., 1., 0., 2., 2., 0.9]], device=DEV)
+    o2p, ranges = gs.map_to_tiles(g, torch.tensor([[0.5], [0.2]], device=DEV), (40, 30), cfg)
+    ref_o2p, ref_ranges = orc.map_to_tiles(g.cpu(), np.array([[0.5], [0.2]], np.float32), (40, 30))
+    assert (pu.to_np(o2p) == ref_o2p).all() and (pu.to_np(ranges) == ref_ranges).all()
+
+
+def test_hip_lib_cumsum_and_sort():
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 1023, 1024, 1025, 100000, 1 << 20):
+        x = rng.integers(0, 50, n).astype(np.int32)
+        out, total = gs.hip_lib.full_cumsum(dev(x))
+        ref = np.concatenate([[0], np.cumsum(x.astype(np.int64))])
+        assert total == ref[-1] and (pu.to_np(out).astype(np.int64) == ref).all()
+    out, total = gs.hip_lib.full_cumsum(torch.zeros((0,), dtype=torch.int32, device=DEV))
+    assert total == 0 and out.shape == (1,)
+    for n, bits, dt in ((1, (0, 64), np.uint64), (5000, (0, 48), np.uint64), (300000, (0, 48), np.uint64),
+                        (70000, (8, 40), np.uint64), (100000, (0, 32), np.uint32), (4097, (0, 20), np.uint32)):
+        keys = rng.integers(0, 1 << 62 if dt == np.uint64 else 1 << 32, n, dtype=np.uint64).astype(dt)
+        keys[rng.integers(0, n, n // 3)] = keys[0]  # plenty of duplicates: stability is observable
+        vals = np.arange(n, dtype=np.int32)
+        tdt = torch.int64 if dt == np.uint64 else torch.int32
+        k_out, v_out = gs.hip_lib.radix_sort_pairs(dev(keys.view(np.int64 if dt == np.uint64 else np.int32), tdt),
+                                                   dev(vals), bits[0], bits[1])
+        mask = (1 << (bits[1] - bits[0])) - 1
+        order = np.argsort(((keys.astype(np.uint64) >> np.uint64(bits[0])) & np.uint64(mask)), kind="stable")
+        assert (pu.to_np(v_out) == vals[order]).all(), f"n={n} bits={bits}"
+        assert (pu.to_np(k_out).view(dt) == keys[order]).all()
+    with pytest.raises(RuntimeError):
+        gs.hip_lib.full_cumsum(torch.zeros(4, device=DEV))
+
+
+# -------------------------------------------------------------------------------- rasterizer
+RASTER_CASES = [(0, 40, (8, 8), 8, 3), (1, 300, (64, 48), 16, 3), (2, 500, (50, 37), 16, 1), (3, 64, (33, 17), 8, 2),
+                (4, 1000, (96, 64), 32, 3), (5, 4000, (320, 200), 16, 5), (6, 800, (128, 72), 16, 8),
+                (7, 300, (48, 48), 16, 12), (8, 20000, (256, 256), 16, 3)]
+
+
+@pytest.mark.parametrize("seed,n,size,tile,F", RASTER_CASES)
+def test_raster_forward_backward(seed, n, size, tile, F):
+    g2d, depth, feat = pu.make_2d_scene(seed, n, size, channels=F, scale_factor=0.5)
+    cfg = RasterConfig(tile_size=tile)
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
+    assert tuple(out.image.shape) == (size[1], size[0], F) and tuple(out.image_weight.shape) == (size[1], size[0])
+    pu.assert_pixels_close(out.image, image_ref, "image")
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    torch.manual_seed(100 + seed)
+    gi = torch.rand(size[1], size[0], F)
+    (out.image * dev(gi)).sum().backward()
+    # the backward consumes the forward's own image: give the oracle the HIP image so that the only
+    # difference measured is the backward kernel
+    gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d")
+    pu.assert_grad_close(f_t.grad, gf, "grad_features")
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_raster_reference_gradcheck_scene(seed):
+    """the reference's own rasterizer test scene (tests/test_rasterizer.py:30-59), f32 vs oracle f64"""
+    torch.manual_seed(seed)
+    n = torch.randint(1, 50, (1,)).item()
+    channels = torch.randint(1, 4, (1,)).item()
+    g = scenes.random_2d_gaussians(n, (8, 8), num_channels=channels, scale_factor=1.0, alpha_range=(0.2, 0.8))
+    g2d = gs.misc.renderer2d.project_gaussians2d(g) if hasattr(gs, "misc") else None
+    from taichi_gaussian_rasterizer_amd.misc.renderer2d import project_gaussians2d
+    g2d = project_gaussians2d(g).float()
+    for antialias in (False, True):
+        cfg = RasterConfig(tile_size=8, pixel_stride=(1, 1), antialias=antialias)
+        o2p = np.arange(n, dtype=np.int32)
+        ranges = np.array([[0, n]], np.int32)
+        image_ref, _, _ = orc.rasterize_with_tiles(g2d.double(), g.feature.double(), o2p, ranges, (8, 8),
+                                                   orc.OracleConfig.of(cfg))
+        g_t, f_t = dev(g2d).requires_grad_(True), dev(g.feature.float()).requires_grad_(True)
+        out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges), (8, 8), cfg)
+        pu.assert_pixels_close(out.image, image_ref, f"image aa={antialias}", atol=5e-5, rtol=5e-5)
+        gi = np.random.default_rng(seed).random((8, 8, channels)).astype(np.float32)
+        (out.image * dev(gi)).sum().backward()
+        gg, gf, _ = orc.rasterize_backward(g2d.double(), g.feature.double(), o2p, ranges, (8, 8), image_ref,
+                                           gi.astype(np.float64), orc.OracleConfig.of(cfg))
+        pu.assert_grad_close(g_t.grad, gg, f"grad_gaussians2d aa={antialias}", tol=1e-3)
+        pu.assert_grad_close(f_t.grad, gf, f"grad_features aa={antialias}", tol=1e-3)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_visibility_and_heuristics(seed):
+    """tests/test_visibility.py:34-64 (visibility == d sum(image)/d feature[:,0]) + oracle parity"""
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(100, 6000))
+    size = (320, 200)
+    g2d, depth, feat = pu.make_2d_scene(seed, n, size, scale_factor=0.2, alpha_range=(0.2, 1.0))
+    cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
+    f_t = dev(feat).requires_grad_(True)
+    g_t = dev(g2d).requires_grad_(True)
+    raster = gs.rasterize(g_t, dev(depth), f_t, size, cfg)
+    raster.image.sum().backward()
+    vis = pu.to_np(raster.visibility)
+    assert vis.shape == (n,)
+    assert np.allclose(pu.to_np(f_t.grad[:, 0]), vis, rtol=1e-4, atol=3e-4)
+    ocfg = orc.OracleConfig.of(cfg)
+    (image_ref, _, vis_ref), (o2p, ranges) = orc.rasterize(g2d, depth, feat, size, ocfg)
+    pu.assert_grad_close(vis, vis_ref, "visibility")
+    _, _, heur_ref = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(raster.image),
+                                            np.ones_like(image_ref), ocfg)
+    pu.assert_grad_close(raster.point_heuristic, heur_ref, "point_heuristic", tol=1e-3)
+
+
+def test_quantile_mode_median_depth():
+    """use_alpha_blending=False + saturate_threshold=0.5 (renderer.py:203-208): forward only"""
+    size = (96, 64)
+    g2d, depth, _ = pu.make_2d_scene(11, 600, size, scale_factor=0.6, alpha_range=(0.3, 0.9))
+    cfg = RasterConfig(use_alpha_blending=False, saturate_threshold=0.5)
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, depth, o2p, ranges, size, ocfg)
+    out = gs.rasterize_with_tiles(dev(g2d), dev(depth), dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
+    pu.assert_pixels_close(out.image, image_ref, "median depth")
+    assert (pu.to_np(out.image_weight) == alpha_ref).mean() > 0.999
+
+
+def test_raster_empty():
+    cfg = RasterConfig()
+    ranges = torch.zeros((6, 2), dtype=torch.int32, device=DEV)
+    out = gs.rasterize_with_tiles(torch.zeros((0, 7), device=DEV), torch.zeros((0, 3), device=DEV),
+                                  torch.zeros((0,), dtype=torch.int32, device=DEV), ranges, (40, 30), cfg)
+    assert tuple(out.image.shape) == (30, 40, 3) and float(out.image.abs().sum()) == 0.0
+    assert float(out.image_weight.abs().sum()) == 0.0
+
+
+# -------------------------------------------------------------------------------- projection
+PROJ = [c for c in projection_cases() if c[1] == np.float32]
+
+
+@pytest.mark.parametrize("name,dt,ins,exp,meta", PROJ, ids=[c[0] for c in PROJ])
+def test_projection_golden(name, dt, ins, exp, meta):
+    """HIP f32 vs the reference torch_lib's f64 values for the same inputs; the bar is the error of
+    the reference's own f32 run against that truth (see tests/test_oracle_golden.py)."""
+    truth = load_cases("projection.npz")[name[:-3] + "f64"]
+    keys = ["position", "log_scaling", "rotation", "alpha_logit", "T_camera_world", "projection"]
+    t = [dev(ins[k]).requires_grad_(True) for k in keys]
+    points, depth, idx = hip_proj.apply(*t, meta["image_size"], meta["depth_range"], blur_cov=meta["blur_cov"])
+    assert idx.dtype == torch.int64
+    assert idx.shape[0] == truth["indexes"].shape[0] and (pu.to_np(idx) == truth["indexes"]).all(), "visible set"
+    if idx.shape[0] == 0:
+        return
+    ref32 = np.abs(pu.cov_form(exp["points"]) - pu.cov_form(truth["points"])).max(0)
+    ours = np.abs(pu.cov_form(points) - pu.cov_form(truth["points"])).max(0)
+    scale = np.abs(pu.cov_form(truth["points"])).max(0)
+    assert (ours <= 4 * ref32 + 1e-5 * scale + 1e-6).all(), f"{ours} vs reference f32 error {ref32}"
+    assert np.allclose(pu.to_np(depth), truth["depth"], rtol=1e-4)
+    (points.mean() + depth.mean()).backward()
+    for tensor, k in zip(t, keys):
+        tr = truth[f"grad_{k}"]
+        s = max(float(np.abs(tr).max()), 1e-30)
+        ref_err = float(np.abs(exp[f"grad_{k}"] - tr).max()) / s
+        our_err = float(np.abs(pu.to_np(tensor.grad) - tr).max()) / s
+        assert our_err <= 4 * ref_err + 2e-4, f"grad {k}: {our_err:.2e} vs reference f32 error {ref_err:.2e}"
+
+
+@pytest.mark.parametrize("seed,n", [(0, 5000), (1, 50000), (2, 300)])
+def test_projection_vs_oracle(seed, n):
+    torch.manual_seed(seed)
+    camera = scenes.random_camera()
+    g = scenes.random_3d_gaussians(n, camera, margin=0.5, scale_factor=0.1)
+    cfg = RasterConfig()
+    args = [*g.shape_tensors(), camera.T_camera_world, camera.projection]
+    p_ref, d_ref, i_ref = orc.project(*args, camera.image_size, camera.depth_range, blur_cov=cfg.blur_cov)
+    t = [dev(a).requires_grad_(True) for a in args]
+    p, d, i, ndc = hip_proj.project_with_ndc(*t, camera.image_size, camera.depth_range, cfg)
+    sym = np.setxor1d(pu.to_np(i), i_ref)
+    assert sym.size <= max(1, n // 20000), f"visible sets differ in {sym.size} gaussians"
+    common, ia, ib = np.intersect1d(pu.to_np(i), i_ref, return_indices=True)
+    assert (np.diff(pu.to_np(i)) > 0).all()
+    pu.assert_grad_close(pu.cov_form(pu.to_np(p)[ia]), pu.cov_form(p_ref[ib]), "points (cov form)", tol=1e-3)
+    assert np.allclose(pu.to_np(d)[ia], d_ref[ib], rtol=1e-5)
+    # ndc depth: bit-exact function of the depth the kernel itself produced
+    assert (pu.to_np(ndc) == orc.ndc_depth(pu.to_np(d), camera.near_plane, camera.far_plane)).all()
+    if sym.size == 0:
+        gen = torch.Generator().manual_seed(seed)
+        gp, gd = torch.rand(p.shape, generator=gen), torch.rand(d.shape, generator=gen)
+        ((p * dev(gp)).sum() + (d * dev(gd)).sum()).backward()
+        grads = orc.project_backward(*args, camera.image_size, i_ref, gp.numpy(), gd.numpy(), blur_cov=cfg.blur_cov)
+        for tensor, ref, k in zip(t, grads, ["position", "log_scaling", "rotation", "alpha_logit", "T", "proj"]):
+            pu.assert_grad_close(tensor.grad, ref, f"d_{k}", tol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------- SH
+SHC = [c for c in sh_cases() if c[1] == np.float32]
+
+
+@pytest.mark.parametrize("name,dt,ins,indexes,exp", SHC, ids=[c[0] for c in SHC])
+def test_sh_golden(name, dt, ins, indexes, exp):
+    """reference bar: atol 1e-5 (tests/util.py:62-63) on outputs and gradients"""
+    params, points, cam = (dev(ins[k]).requires_grad_(True) for k in ("params", "points", "camera_pos"))
+    out = gs.evaluate_sh_at(params, points, dev(indexes), cam)
+    assert np.allclose(pu.to_np(out), exp["out"], atol=1e-5)
+    out.mean().backward()
+    assert np.allclose(pu.to_np(params.grad), exp["grad_params"], atol=1e-5)
+    assert np.allclose(pu.to_np(points.grad), exp["grad_points"], atol=1e-5, rtol=1e-4)
+    assert np.allclose(pu.to_np(cam.grad), exp["grad_camera_pos"], atol=1e-5, rtol=1e-4)
+
+
+# -------------------------------------------------------------------------- render_gaussians
+@pytest.mark.parametrize("seed,n,size,deg,depth_mode", [(0, 2000, (160, 120), 3, False), (1, 20000, (320, 240), 3, True),
+                                                        (2, 5000, (200, 200), 0, False), (3, 3000, (129, 65), 2, True)])
+def test_render_gaussians_vs_oracle(seed, n, size, deg, depth_mode):
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=deg, seed=seed)
+    cfg = RasterConfig()
+    gen = torch.Generator().manual_seed(seed + 7)
+    gi = torch.rand(size[1], size[0], 3, generator=gen)
+    gdm, gvm = torch.rand(size[1], size[0], generator=gen), torch.rand(size[1], size[0], generator=gen)
+    grads = dict(image=gi.numpy())
+    if depth_mode:
+        grads.update(depth=gdm.numpy(), depth_var=gvm.numpy() * 0.1)
+    ref = pu.oracle_render(g, camera, cfg, use_sh=True, render_depth=depth_mode, grads=grads)
+
+    gd = g.to(DEV).requires_grad_(True)
+    cam = camera.to(device=DEV)
+    r = gs.render_gaussians(gd, cam, cfg, use_sh=True, render_depth=depth_mode)
+    assert (pu.to_np(r.points_in_view) == ref["indexes"]).all()
+    pu.assert_pixels_close(r.image, ref["image"], "image")
+    pu.assert_pixels_close(r.image_weight, ref["alpha"], "image_weight")
+    loss = (r.image * dev(gi)).sum()
+    if depth_mode:
+        pu.assert_pixels_close(r.depth, ref["depth_img"], "depth", atol=1e-4, rtol=1e-4)
+        loss = loss + (r.depth * dev(gdm)).sum() + (r.depth_var * dev(gvm) * 0.1).sum()
+    loss.backward()
+    for name, key in (("position", "d_position"), ("log_scaling", "d_log_scaling"), ("rotation", "d_rotation"),
+                      ("alpha_logit", "d_alpha_logit"), ("feature", "d_feature")):
+        pu.assert_grad_close(getattr(gd, name).grad, ref[key], f"grad {name}", tol=2e-3)
