@@ -46,6 +46,20 @@ def assert_grad_close(hip, ref, name, tol=GRAD_TOL):
     assert err <= tol, f"{name}: normwise error {err:.3e} > {tol:.1e} (scale {scale:.3e})"
 
 
+def assert_rows_close(hip, ref, name, tol=5e-2, frac=0.995):
+    """row-wise (per Gaussian) relative comparison that tolerates a few ill-conditioned rows: the
+    eigen-decomposition adjoint divides by the eigenvalue gap, so for a near-isotropic splat f32
+    noise in the upstream gradient is amplified without bound in ANY f32 implementation."""
+    hip, ref = to_np(hip).astype(np.float64), to_np(ref).astype(np.float64)
+    hip, ref = hip.reshape(hip.shape[0], -1), ref.reshape(ref.shape[0], -1)
+    assert np.isfinite(hip).all(), f"{name}: non-finite values"
+    err = np.linalg.norm(hip - ref, axis=1)
+    mag = np.linalg.norm(ref, axis=1)
+    floor = 1e-3 * float(np.median(mag[mag > 0])) if (mag > 0).any() else 1e-20
+    ok = err <= tol * (mag + floor)
+    assert ok.mean() >= frac, f"{name}: only {ok.mean():.4f} of rows within {tol} (need {frac})"
+
+
 def cov_form(points):
     """(mean.xy, cov00, cov01, cov11, alpha): well-conditioned form of the packed 2D gaussian."""
     p = to_np(points).astype(np.float64)

@@ -247,9 +247,17 @@ def test_projection_vs_oracle(seed, n):
         gen = torch.Generator().manual_seed(seed)
         gp, gd = torch.rand(p.shape, generator=gen), torch.rand(d.shape, generator=gen)
         ((p * dev(gp)).sum() + (d * dev(gd)).sum()).backward()
-        grads = orc.project_backward(*args, camera.image_size, i_ref, gp.numpy(), gd.numpy(), blur_cov=cfg.blur_cov)
-        for tensor, ref, k in zip(t, grads, ["position", "log_scaling", "rotation", "alpha_logit", "T", "proj"]):
-            pu.assert_grad_close(tensor.grad, ref, f"d_{k}", tol=2e-3)
+        # f32 gradients of these far-away random cameras are ill-conditioned (the reference's own f32
+        # run is ~1e-3 off its f64 run): measure both f32 implementations against the oracle in f64
+        args64 = [a.double() for a in args]
+        truth = orc.project_backward(*args64, camera.image_size, i_ref, gp.double().numpy(), gd.double().numpy(),
+                                     blur_cov=cfg.blur_cov)
+        cpu32 = orc.project_backward(*args, camera.image_size, i_ref, gp.numpy(), gd.numpy(), blur_cov=cfg.blur_cov)
+        for tensor, tr, c32, k in zip(t, truth, cpu32, ["position", "log_scaling", "rotation", "alpha_logit", "T", "proj"]):
+            s = max(float(np.abs(tr).max()), 1e-30)
+            cpu_err = float(np.abs(c32 - tr).max()) / s
+            hip_err = float(np.abs(pu.to_np(tensor.grad) - tr).max()) / s
+            assert hip_err <= 4 * cpu_err + 2e-4, f"d_{k}: HIP f32 error {hip_err:.2e} vs CPU f32 error {cpu_err:.2e}"
 
 
 # ---------------------------------------------------------------------------------------- SH
@@ -269,30 +277,118 @@ def test_sh_golden(name, dt, ins, indexes, exp):
 
 
 # -------------------------------------------------------------------------- render_gaussians
-@pytest.mark.parametrize("seed,n,size,deg,depth_mode", [(0, 2000, (160, 120), 3, False), (1, 20000, (320, 240), 3, True),
-                                                        (2, 5000, (200, 200), 0, False), (3, 3000, (129, 65), 2, True)])
-def test_render_gaussians_vs_oracle(seed, n, size, deg, depth_mode):
+E2E_CASES = [(0, 2000, (160, 120), 3, False), (1, 20000, (320, 240), 3, True), (2, 5000, (200, 200), 0, False),
+             (3, 3000, (129, 65), 2, True)]
+
+
+@pytest.mark.parametrize("seed,n,size,deg,depth_mode", E2E_CASES)
+def test_render_gaussians_stagewise(seed, n, size, deg, depth_mode):
+    """render_gaussians == the composition of the HIP operators, and every stage of that composition
+    matches the oracle when the oracle is fed the HIP stage's own inputs (tight tolerances: no
+    compounding of f32 rounding through the pipeline)."""
     g, camera = scenes.benchmark_scene(n, size, sh_degree=deg, seed=seed)
     cfg = RasterConfig()
+    ocfg = orc.OracleConfig.of(cfg)
     gen = torch.Generator().manual_seed(seed + 7)
     gi = torch.rand(size[1], size[0], 3, generator=gen)
-    gdm, gvm = torch.rand(size[1], size[0], generator=gen), torch.rand(size[1], size[0], generator=gen)
-    grads = dict(image=gi.numpy())
-    if depth_mode:
-        grads.update(depth=gdm.numpy(), depth_var=gvm.numpy() * 0.1)
-    ref = pu.oracle_render(g, camera, cfg, use_sh=True, render_depth=depth_mode, grads=grads)
-
+    gdm, gvm = torch.rand(size[1], size[0], generator=gen), torch.rand(size[1], size[0], generator=gen) * 0.1
     gd = g.to(DEV).requires_grad_(True)
     cam = camera.to(device=DEV)
-    r = gs.render_gaussians(gd, cam, cfg, use_sh=True, render_depth=depth_mode)
-    assert (pu.to_np(r.points_in_view) == ref["indexes"]).all()
-    pu.assert_pixels_close(r.image, ref["image"], "image")
-    pu.assert_pixels_close(r.image_weight, ref["alpha"], "image_weight")
+
+    # --- the composition, holding on to the intermediates
+    g2d, depths, idx, ndc = hip_proj.project_with_ndc(*gd.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                      cam.image_size, cam.depth_range, cfg)
+    feats = gs.evaluate_sh_at(gd.feature, gd.position.detach(), idx, cam.camera_position)
+    g2d.retain_grad(); depths.retain_grad(); feats.retain_grad()
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    r = render_projected(idx, g2d, feats, depths, cam, cfg, render_depth=depth_mode, ndc_depths=ndc)
     loss = (r.image * dev(gi)).sum()
     if depth_mode:
-        pu.assert_pixels_close(r.depth, ref["depth_img"], "depth", atol=1e-4, rtol=1e-4)
-        loss = loss + (r.depth * dev(gdm)).sum() + (r.depth_var * dev(gvm) * 0.1).sum()
+        loss = loss + (r.depth * dev(gdm)).sum() + (r.depth_var * dev(gvm)).sum()
     loss.backward()
+
+    # --- render_gaussians is exactly this composition
+    r2 = gs.render_gaussians(g.to(DEV), cam, cfg, use_sh=True, render_depth=depth_mode)
+    assert torch.equal(r2.image, r.image) and torch.equal(r2.points_in_view, idx)
+    assert torch.equal(r2.gaussians2d, g2d.detach())
+
+    # --- stage: SH, given the HIP index list
+    cam_pos = pu.to_np(cam.camera_position)
+    f_ref = orc.evaluate_sh_at(g.feature.numpy(), g.position.numpy(), pu.to_np(idx), cam_pos)
+    assert np.allclose(pu.to_np(feats), f_ref, atol=1e-5)
+
+    # --- stage: mapper, given HIP points + ndc depth: bit-exact
+    p_np, d_np, ndc_np = pu.to_np(g2d), pu.to_np(depths), pu.to_np(ndc)
+    assert (ndc_np == orc.ndc_depth(d_np, camera.near_plane, camera.far_plane)).all()
+    o2p_ref, ranges_ref = orc.map_to_tiles(p_np, ndc_np, size, ocfg)
+    o2p, ranges = gs.map_to_tiles(g2d.detach(), ndc, size, cfg)
+    assert (pu.to_np(o2p) == o2p_ref).all() and (pu.to_np(ranges) == ranges_ref).all()
+
+    # --- stage: rasterizer forward/backward, given HIP points/features
+    f_np = pu.to_np(feats)
+    feats_r = np.concatenate([d_np, d_np ** 2, f_np], 1).astype(np.float32) if depth_mode else f_np
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(p_np, feats_r, o2p_ref, ranges_ref, size, ocfg)
+    g_img = np.zeros_like(image_ref)
+    if depth_mode:
+        pu.assert_pixels_close(r.image, image_ref[..., 2:], "image")
+        w = alpha_ref + np.float32(1e-6)
+        d_img = image_ref[..., 0] / w
+        pu.assert_pixels_close(r.depth, d_img, "depth", atol=1e-4, rtol=1e-4)
+        pu.assert_pixels_close(r.depth_var, image_ref[..., 1] / w - d_img ** 2, "depth_var", atol=2e-3, rtol=1e-3)
+        hip_img = np.concatenate([pu.to_np(r.depth * (r.image_weight + 1e-6))[..., None],
+                                  pu.to_np((r.depth_var + r.depth ** 2) * (r.image_weight + 1e-6))[..., None],
+                                  pu.to_np(r.image)], -1)
+        w_h = pu.to_np(r.image_weight) + np.float32(1e-6)
+        d_h = pu.to_np(r.depth)
+        g_img[..., 2:] = gi.numpy()
+        g_img[..., 0] = (gdm.numpy() - 2 * d_h * gvm.numpy()) / w_h
+        g_img[..., 1] = gvm.numpy() / w_h
+    else:
+        pu.assert_pixels_close(r.image, image_ref, "image")
+        hip_img = pu.to_np(r.image)
+        g_img[...] = gi.numpy()
+    pu.assert_pixels_close(r.image_weight, alpha_ref, "image_weight")
+    gg, gf, _ = orc.rasterize_backward(p_np, feats_r, o2p_ref, ranges_ref, size, hip_img.astype(np.float32), g_img, ocfg)
+    gdepth_ref = np.zeros_like(d_np)
+    if depth_mode:
+        gdepth_ref = gf[:, 0:1] + 2 * d_np * gf[:, 1:2]
+        gf = gf[:, 2:]
+        pu.assert_grad_close(depths.grad, gdepth_ref, "d depth", tol=1e-3)
+    pu.assert_grad_close(g2d.grad, gg, "d gaussians2d", tol=1e-3)
+    pu.assert_grad_close(feats.grad, gf, "d features", tol=1e-3)
+
+    # --- stage: projection / SH backward, given the HIP upstream gradients
+    args = [*g.shape_tensors(), camera.T_camera_world, camera.projection]
+    up_d = pu.to_np(depths.grad) if depths.grad is not None else np.zeros_like(d_np)
+    args64 = [a.double() for a in args]
+    truth = orc.project_backward(*args64, size, pu.to_np(idx), pu.to_np(g2d.grad).astype(np.float64),
+                                 up_d.astype(np.float64), blur_cov=cfg.blur_cov)
+    cpu32 = orc.project_backward(*args, size, pu.to_np(idx), pu.to_np(g2d.grad), up_d, blur_cov=cfg.blur_cov)
+    for name, tr, c32 in zip(("position", "log_scaling", "rotation", "alpha_logit"), truth, cpu32):
+        sc = max(float(np.abs(tr).max()), 1e-30)
+        cpu_err = float(np.abs(c32 - tr).max()) / sc
+        hip_err = float(np.abs(pu.to_np(getattr(gd, name).grad) - tr).max()) / sc
+        assert hip_err <= 4 * cpu_err + 2e-4, f"d_{name}: HIP f32 error {hip_err:.2e} vs CPU f32 error {cpu_err:.2e}"
+    dfeat_ref, _, _ = orc.evaluate_sh_at_backward(g.feature.numpy(), g.position.numpy(), pu.to_np(idx), cam_pos,
+                                                  pu.to_np(feats.grad))
+    assert np.allclose(pu.to_np(gd.feature.grad), dfeat_ref, atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("seed,n,size,deg,depth_mode", E2E_CASES)
+def test_render_gaussians_end_to_end_vs_oracle(seed, n, size, deg, depth_mode):
+    """whole pipeline on the GPU vs whole pipeline on the CPU oracle.  f32 rounding of the projected
+    means (1e-7 * ~1e3 px) is amplified by the blend, so the end-to-end bar is looser than the
+    per-stage one (see the stagewise test for the tight comparison)."""
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=deg, seed=seed)
+    cfg = RasterConfig()
+    gi = torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(seed + 7))
+    ref = pu.oracle_render(g, camera, cfg, use_sh=True, render_depth=depth_mode, grads=dict(image=gi.numpy()))
+    gd = g.to(DEV).requires_grad_(True)
+    r = gs.render_gaussians(gd, camera.to(device=DEV), cfg, use_sh=True, render_depth=depth_mode)
+    assert (pu.to_np(r.points_in_view) == ref["indexes"]).all()
+    pu.assert_pixels_close(r.image, ref["image"], "image", atol=1e-3, rtol=1e-3)
+    pu.assert_pixels_close(r.image_weight, ref["alpha"], "image_weight", atol=1e-3, rtol=1e-3)
+    (r.image * dev(gi)).sum().backward()
     for name, key in (("position", "d_position"), ("log_scaling", "d_log_scaling"), ("rotation", "d_rotation"),
                       ("alpha_logit", "d_alpha_logit"), ("feature", "d_feature")):
-        pu.assert_grad_close(getattr(gd, name).grad, ref[key], f"grad {name}", tol=2e-3)
+        pu.assert_rows_close(getattr(gd, name).grad, ref[key], f"grad {name}")
