@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the render path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload c3]
+
+Metric (BASELINE.json): Mpixels/s of one forward+backward `render_gaussians` frame.
+Workloads (BASELINE.json configs / SURVEY.md 8d, synthetic seeded scene, random-init parameters):
+    c2: 200k Gaussians, 1920x1080, SH deg 0, forward only
+    c3: 1M Gaussians, 2048x2048, SH deg 3, forward+backward            (default; the headline)
+    c4: c3 + depth / depth-variance feature render (F = 5)
+    c5: 6M Gaussians, 4096x4096, SH deg 3, forward+backward
+A step = one frame: forward, loss = sum(image * G) (+ depth terms for c4), backward; inputs are
+resident in HBM before the timed region.  N > 1 (launched by torch.distributed.run, one rank per
+GPU over RCCL): the SAME frame is sharded by tile-row strips with one all-reduce of per-Gaussian
+gradients (taichi_gaussian_rasterizer_amd/parallel.py) -> "scaling": "strong".
+
+Rank 0 prints ONE JSON line.  Beyond the driver's contract it carries
+  roofline     : the dominant kernel's achieved algorithmic bytes/s (HIP events on the launch stream
+                 inside the timed region) against the 8 TB/s HBM peak,
+  cpu_baseline : the CPU oracle (oracle/, "port" of the same algorithm, OpenMP) timed on this host,
+  stages_ms    : per C-ABI entry point GPU time per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    "c2": dict(n=200_000, size=(1920, 1080), sh_degree=0, backward=False, depth=False),
+    "c3": dict(n=1_000_000, size=(2048, 2048), sh_degree=3, backward=True, depth=False),
+    "c4": dict(n=1_000_000, size=(2048, 2048), sh_degree=3, backward=True, depth=True),
+    "c5": dict(n=6_000_000, size=(4096, 4096), sh_degree=3, backward=True, depth=False),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def algorithmic_bytes(N, V, K, T, P, F, C, D):
+    """Compulsory HBM bytes per launch of each stage (every stage reads its inputs
+    once and writes its outputs once; atomics counted once per (tile, splat))."""
+    return {
+        "gs_project_fwd": 44 * N + 64 * N + 48 * V + 4 * N,          # inputs, staging w+r, compact rows, slot map
+        "gs_sh_fwd": V * (8 + 12 + 4 * C * D + 4 * C),
+        "gs_map_prepare": 28 * V + 16 * T,
+        "gs_map_finish": 32 * V + 8 * K + 8 * K + 4 * K + 8 * T,     # query again, bucket w, sort r, order w
+        "gs_raster_fwd": 8 * T + K * (4 + 28 + 4 * F) + 4 * P * (F + 1),
+        "gs_raster_bwd": 8 * T + K * (4 + 28 + 4 * F) + 8 * P * F + 4 * (7 + F) * K,
+        "gs_raster_bwd_unpack": V * (64 + 4 * (7 + F)),
+        "gs_sh_bwd": V * (8 + 12 + 4 * C * D + 4 * C) + 2 * 4 * C * D * N,
+        "gs_project_bwd": 44 * N + 4 * N + 32 * V + 44 * N,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=2)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path in the product"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    import taichi_gaussian_rasterizer_amd as gs
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    from taichi_gaussian_rasterizer_amd import RasterConfig, parallel, scenes
+
+    wl = WORKLOADS[args.workload]
+    W, H = wl["size"]
+    cfg = RasterConfig()
+    g_cpu, cam_cpu = scenes.benchmark_scene(wl["n"], wl["size"], sh_degree=wl["sh_degree"], seed=0)
+    g = g_cpu.to(dev)
+    if wl["backward"]:
+        g.requires_grad_(True)
+    cam = cam_cpu.to(device=dev)
+    gen = torch.Generator().manual_seed(1)
+    G = torch.rand(H, W, 3, generator=gen).to(dev)
+    Gd = torch.rand(H, W, generator=gen).to(dev) if wl["depth"] else None
+    Gv = (torch.rand(H, W, generator=gen) * 0.1).to(dev) if wl["depth"] else None
+    info = {}
+
+    def step():
+        if wl["backward"]:
+            for _, t in g.items():
+                t.grad = None
+        if world > 1:
+            r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=wl["depth"])
+            y0, y1 = r.strip
+        else:
+            r = gs.render_gaussians(g, cam, cfg, use_sh=True, render_depth=wl["depth"])
+            y0, y1 = 0, H
+        info["V"] = int(r.points_in_view.shape[0])
+        if not wl["backward"]:
+            return r
+        loss = (r.image * G[y0:y1]).sum()
+        if wl["depth"]:
+            loss = loss + (r.depth * Gd[y0:y1]).sum() + (r.depth_var * Gv[y0:y1]).sum()
+        loss.backward()
+        return r
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    nv.timer.reset()
+    nv.timer.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    nv.timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    # ---- scene statistics for the byte formulas (untimed)
+    with torch.no_grad():
+        from taichi_gaussian_rasterizer_amd.perspective.projection import project_with_ndc
+        p2d, _, _, ndc = project_with_ndc(*[t.detach() for t in g.shape_tensors()], cam.T_camera_world,
+                                          cam.projection, cam.image_size, cam.depth_range, cfg)
+        o2p, ranges = gs.map_to_tiles(p2d, ndc, (W, H), cfg)
+        V, K, T = int(p2d.shape[0]), int(o2p.shape[0]), int(ranges.shape[0] * ranges.shape[1])
+    F = 5 if wl["depth"] else 3
+    D = (wl["sh_degree"] + 1) ** 2
+    by = algorithmic_bytes(wl["n"], V, K, T, W * H, F, 3, D)
+
+    stages = {}
+    roofline = None
+    if nv.timer.records:
+        for name, (calls, total_ms) in nv.timer.summary().items():
+            stages[name] = dict(calls_per_step=calls / args.steps, ms_per_step=total_ms / args.steps,
+                                avg_launch_ms=total_ms / calls)
+        dom = max(stages, key=lambda k: stages[k]["ms_per_step"])
+        if dom in by:
+            # under sharding a launch covers 1/world of the tiles: scale the per-launch bytes accordingly
+            per_launch = by[dom] / (world if dom.startswith(("gs_raster", "gs_map_finish")) else 1)
+            achieved = per_launch / (stages[dom]["avg_launch_ms"] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                            algorithmic_bytes_per_launch=int(per_launch),
+                            avg_launch_ms=round(stages[dom]["avg_launch_ms"], 4))
+            pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(pmc):  # HBM bytes per launch from rocprofv3 --pmc passes (see profiles/README.md)
+                try:
+                    rec = json.load(open(pmc)).get(args.workload, {}).get(dom)
+                    if rec and world == 1:
+                        roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+    whole = sum(v for k, v in by.items() if wl["backward"] or not k.endswith(("_bwd", "_unpack")))
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_baseline = run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, args.cpu_frames)
+        except Exception as e:  # the oracle is test infrastructure; its absence must not fail the bench
+            cpu_baseline = dict(error=f"{type(e).__name__}: {e}")
+
+    if rank == 0:
+        out = {
+            "metric": "Mpixels/s fwd+bwd @ 2048x2048, 1M Gaussians" if args.workload == "c3"
+                      else f"Mpixels/s ({args.workload})",
+            "value": round(W * H / (ms_per_step * 1e-3) / 1e6, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {wl['n']} Gaussians, {W}x{H}, SH deg {wl['sh_degree']}, "
+                                   f"tile 16, {'fwd+bwd' if wl['backward'] else 'fwd'}"
+                                   f"{', depth features' if wl['depth'] else ''}",
+                       "visible": V, "overlaps": K, "tiles": T,
+                       "parallelism": "single GPU" if world == 1 else f"tile-row strips x{world} + grad all-reduce"},
+            "roofline": roofline,
+            "cpu_baseline": cpu_baseline,
+            "whole_path": {"algorithmic_bytes_per_frame": int(whole),
+                           "hbm_frac": round(whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+            "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, frames):
+    """The CPU oracle (the C++/OpenMP restatement in oracle/) on the same scene, all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import parity_util as pu
+    from oracle import oracle as orc
+    cores = os.cpu_count() or 1
+    orc.set_num_threads(cores)
+    W, H = wl["size"]
+    gi = np.random.default_rng(1).random((H, W, 3)).astype(np.float32)
+    grads = dict(image=gi) if wl["backward"] else None
+    if wl["depth"] and grads is not None:
+        grads.update(depth=np.random.default_rng(2).random((H, W)).astype(np.float32),
+                     depth_var=np.random.default_rng(3).random((H, W)).astype(np.float32) * 0.1)
+    best = None
+    for _ in range(max(1, frames)):
+        t0 = time.perf_counter()
+        pu.oracle_render(g_cpu, cam_cpu, cfg, use_sh=True, render_depth=wl["depth"], grads=grads)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return dict(value=round(W * H / best / 1e6, 3), unit="Mpix/s", cores=orc.num_threads(), kind="port",
+                sample=f"the full workload, best of {max(1, frames)} frames, no warm-up "
+                       f"({best:.2f} s/frame, OpenMP over {orc.num_threads()} threads)")
+
+
+if __name__ == "__main__":
+    main()

@@ -61,6 +61,49 @@ SIGNATURES = {
 _lib = None
 
 
+class KernelTimer:
+    """Optional per-entry-point GPU timing with HIP events recorded on the launch stream
+    (bench.py uses it to measure the dominant kernel live inside the timed region)."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}  # name -> list of (start_event, end_event)
+
+    def reset(self):
+        self.records = {}
+
+    def summary(self):
+        """name -> (calls, total_ms); call after torch.cuda.synchronize()."""
+        return {name: (len(ev), sum(a.elapsed_time(b) for a, b in ev)) for name, ev in self.records.items()}
+
+
+timer = KernelTimer()
+
+
+class _TimedLib:
+    """Attribute access returns the ctypes function; launches are bracketed by events when
+    `timer.enabled` (size queries and gs_last_error are never timed)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    def __getattr__(self, name):
+        fn = getattr(self._h, name)
+        if name.endswith("_bytes") or name in ("gs_last_error", "gs_version", "gs_grad_row_floats"):
+            return fn
+
+        def call(*args):
+            if not timer.enabled:
+                return fn(*args)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            rc = fn(*args)
+            b.record()
+            timer.records.setdefault(name, []).append((a, b))
+            return rc
+        return call
+
+
 def build(force: bool = False, jobs: int = 6) -> str:
     """Compile libgsplat_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     args = ["make", "-C", CSRC, f"-j{jobs}"]
@@ -72,7 +115,7 @@ def build(force: bool = False, jobs: int = 6) -> str:
     return LIB_PATH
 
 
-def lib() -> ctypes.CDLL:
+def lib():
     """Load the HIP library; raise loudly if it is not there (no fallback exists)."""
     global _lib
     if _lib is None:
@@ -86,7 +129,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = restype
             fn.argtypes = argtypes
-        _lib = handle
+        _lib = _TimedLib(handle)
     return _lib
 
 
