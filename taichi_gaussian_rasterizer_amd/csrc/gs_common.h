@@ -72,6 +72,49 @@ __device__ __forceinline__ float gs_wave_sum_to_lane63(float x) {
   return x;
 }
 
+template <int CTRL>
+__device__ __forceinline__ float gs_dpp_add_full(float x) {
+  // x + dpp(x) with full row/bank masks: the form hipcc fuses into ONE v_add_f32_dpp
+  return x + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), CTRL, 0xf, 0xf, true));
+}
+
+// Transposed butterfly reduction of 16 per-lane values over the 64 lanes of the wave.
+// On return, lane l holds the wave total of value (l >> 2); 35 VALU instructions for 16 values,
+// against 6 per value (96) for independent DPP reductions.  Each stage halves the number of lanes a
+// value is spread over while packing twice as many values into a register:
+//   A  v_permlane32_swap: (v[i], v[i+8]) -> lanes 0-31 carry value i, lanes 32-63 value i+8
+//   B  v_permlane16_swap: rows (16 lanes) carry values i, i+4, i+8, i+12
+//   C  row_ror:8 + select: half-rows     D  row_half_mirror + select: quads
+//   E  quad_perm xor-1, xor-2: every lane of a quad holds the total
+__device__ __forceinline__ float gs_wave_reduce16_transposed(float (&v)[16], int lane) {
+  float a[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i + 8]), false, false);
+    a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  float b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(a[i + 4]), false, false);
+    b[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
+  float c[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float t = gs_dpp_add_full<0x128>(b[i]);      // row_ror:8
+    const float u = gs_dpp_add_full<0x128>(b[i + 2]);
+    c[i] = hi8 ? u : t;
+  }
+  const float t = gs_dpp_add_full<0x141>(c[0]);        // row_half_mirror
+  const float u = gs_dpp_add_full<0x141>(c[1]);
+  float d = hi4 ? u : t;
+  d = gs_dpp_add_full<0xB1>(d);                        // quad_perm:[1,0,3,2]
+  d = gs_dpp_add_full<0x4E>(d);                        // quad_perm:[2,3,0,1]
+  return d;
+}
+
 __device__ __forceinline__ float gs_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float gs_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
 

@@ -243,14 +243,19 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
 
       // reduce over the wave only if some pixel took a gradient (backward.py:204)
       if (__ballot(has_grad) != 0ull) {
-        float tot[NACC];
+        // transposed butterfly: 16 values at a time, lane l ends up with the total of value l>>2,
+        // and one ds_write_b32 (16 active lanes) stores them
 #pragma unroll
-        for (int c = 0; c < NS; ++c) tot[c] = gs_wave_sum_to_lane63(S[c]);
+        for (int base = 0; base < NACC; base += 16) {
+          float vals[16];
 #pragma unroll
-        for (int c = 0; c < FP; ++c) tot[NS + c] = gs_wave_sum_to_lane63(gf[c]);
-        if (lane == 63) {
-#pragma unroll
-          for (int c = 0; c < NACC; ++c) s_acc[j][c] = tot[c];
+          for (int c = 0; c < 16; ++c) {
+            const int k = base + c;
+            vals[c] = k < NS ? S[k < NS ? k : 0] : (k < NACC ? gf[(k - NS) < FP && k >= NS ? (k - NS) : 0] : 0.0f);
+          }
+          const float tot = gs_wave_reduce16_transposed(vals, lane);
+          const int k = base + (lane >> 2);
+          if ((lane & 3) == 0 && k < NACC) s_acc[j][k] = tot;
         }
       }
     }
