@@ -13,7 +13,7 @@
 //   scan    : single workgroup exclusive scan of the histogram -> tile_ranges, cursors, K, max.
 //   emit    : the query again; slot = returning atomic on the tile's cursor; writes the 64-bit
 //             composite (depth key << 32 | gaussian index) into the tile's bucket.
-//   sort    : one workgroup per tile sorts its bucket in LDS (bitonic on the composite key).
+//   sort    : one wave per tile rank-sorts its bucket (bitonic in LDS / global for crowded tiles).
 //             The composite makes the result independent of the atomic arrival order and equal
 //             to the reference's stable radix sort of (tile << 32 | depth) in generation order.
 // HBM traffic: K*8 B written by emit, K*8 B read + K*4 B written by sort, against
@@ -214,6 +214,49 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const
   }
 }
 
+// Rank sort, one WAVE per tile, for buckets of up to 64*R pairs (the common case: a few hundred
+// splats per tile).  Keys are unique (the Gaussian index is the low word), so the rank of a key
+// -- the number of keys below it -- is its final position: each lane keeps R keys in registers,
+// every key of the bucket is broadcast from LDS once (one wave-uniform ds_read_b64), and lanes
+// count.  n^2/64 compares per tile, no barriers, no data-dependent control flow; ~5x faster than
+// the LDS bitonic network at these sizes.
+template <int R>
+__global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const int2* tile_ranges,
+                                                            const uint64_t* pairs, int* o2p, uint64_t* keys_out,
+                                                            int depth16) {
+  __shared__ uint64_t s_key[64 * R];
+  const int tile = gs_xcd_remap(blockIdx.x, num_tiles);
+  if (tile < 0) return;
+  const int2 r = tile_ranges[tile];
+  const int n = r.y - r.x;
+  if (n <= 0) return;
+  const uint64_t* seg = pairs + r.x;
+  const int lane = threadIdx.x;
+  uint64_t mine[R];
+  int rank[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int i = q * 64 + lane;
+    mine[q] = i < n ? seg[i] : ~0ull;
+    rank[q] = 0;
+    if (i < n) s_key[i] = mine[q];
+  }
+  __syncthreads();
+  for (int j = 0; j < n; ++j) {
+    const uint64_t kj = s_key[j];
+#pragma unroll
+    for (int q = 0; q < R; ++q) rank[q] += kj < mine[q] ? 1 : 0;
+  }
+  const int shift = depth16 ? 16 : 32;
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (q * 64 + lane < n) {
+      o2p[r.x + rank[q]] = int(uint32_t(mine[q]));
+      if (keys_out) keys_out[r.x + rank[q]] = (mine[q] >> 32) | (uint64_t(uint32_t(tile)) << shift);
+    }
+  }
+}
+
 // ---- reference-shaped primitives ----------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_count_kernel(MapArgs a, int* counts) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -395,9 +438,15 @@ extern "C" int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const
   GS_CHECK_LAUNCH("gs_map_finish/emit");
   const int grid = 8 * int(gs_div_up(num_tiles, 8));
   const int2* r = reinterpret_cast<const int2*>(tile_ranges);
-  if (max_tile_count <= 512)
-    hipLaunchKernelGGL((tile_sort_kernel<64, 512>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
+  if (max_tile_count <= 256)
+    hipLaunchKernelGGL((tile_rank_sort_kernel<4>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
                        sorted_keys, use_depth16);
+  else if (max_tile_count <= 512)
+    hipLaunchKernelGGL((tile_rank_sort_kernel<8>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
+                       sorted_keys, use_depth16);
+  else if (max_tile_count <= 1024)
+    hipLaunchKernelGGL((tile_rank_sort_kernel<16>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs,
+                       overlap_to_point, sorted_keys, use_depth16);
   else if (max_tile_count <= 2048)
     hipLaunchKernelGGL((tile_sort_kernel<256, 2048>), dim3(grid), dim3(256), 0, s, num_tiles, r, pairs,
                        overlap_to_point, sorted_keys, use_depth16);

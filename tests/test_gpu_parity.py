@@ -29,7 +29,8 @@ def dev(x, dtype=None):
 # ------------------------------------------------------------------------------------ mapper
 MAPPER_CASES = [(0, 500, (320, 200), 16, False), (1, 2000, (257, 131), 16, False), (2, 300, (64, 64), 8, True),
                 (3, 50, (100, 40), 32, False), (4, 20000, (640, 360), 16, False), (5, 3000, (96, 96), 16, True),
-                (6, 1, (16, 16), 16, False), (7, 5000, (40, 24), 8, False)]
+                (6, 1, (16, 16), 16, False), (7, 5000, (40, 24), 8, False), (8, 3000, (48, 32), 16, False),
+                (9, 12000, (64, 48), 16, False)]
 
 
 @pytest.mark.parametrize("seed,n,size,tile,depth16", MAPPER_CASES)
