@@ -1,0 +1,139 @@
+"""Host-side mirror of the reference operator API: types, validation, error behaviour.
+No GPU: the operators must refuse CPU tensors loudly (there is no CPU path in the product)."""
+import dataclasses
+
+import pytest
+import torch
+
+import taichi_gaussian_rasterizer_amd as gs
+from taichi_gaussian_rasterizer_amd import (CameraParams, Gaussians2D, Gaussians3D, RasterConfig, Rendering,
+                                            TaichiQueue, pad_to_tile, scenes, taichi_queue)
+from taichi_gaussian_rasterizer_amd.taichi_queue import queued
+
+
+def test_public_names_match_reference_init():
+    # reference taichi_splatting/__init__.py:17-33
+    for name in ("render_gaussians", "Rendering", "map_to_tiles", "pad_to_tile", "Gaussians2D", "Gaussians3D",
+                 "RasterConfig", "evaluate_sh_at", "rasterize", "rasterize_with_tiles", "perspective", "TaichiQueue"):
+        assert hasattr(gs, name), name
+    assert hasattr(gs.perspective, "project_to_image") and hasattr(gs.perspective, "CameraParams")
+    assert hasattr(gs.cuda_lib, "full_cumsum") and hasattr(gs.cuda_lib, "radix_sort_pairs")
+
+
+def test_raster_config_defaults_and_hashing():
+    c = RasterConfig()
+    assert (c.tile_size, c.pixel_stride, c.clamp_margin, c.antialias, c.blur_cov) == (16, (2, 2), 0.15, False, 0.3)
+    assert (c.clamp_max_alpha, c.saturate_threshold, c.use_alpha_blending) == (0.99, 0.9999, True)
+    assert abs(c.alpha_threshold - 1 / 255) < 1e-12 and not c.compute_visibility and not c.compute_point_heuristic
+    assert hash(c) == hash(RasterConfig()) and c == RasterConfig()
+    with pytest.raises(dataclasses.FrozenInstanceError):
+        c.tile_size = 8
+    with pytest.raises(TypeError):
+        RasterConfig(tile_size=16.0)
+    with pytest.raises(TypeError):
+        RasterConfig(16)  # kw_only, as the reference
+    assert dataclasses.replace(c, use_alpha_blending=False, saturate_threshold=0.5).saturate_threshold == 0.5
+
+
+def test_gaussians3d_record():
+    torch.manual_seed(0)
+    cam = scenes.random_camera()
+    g = scenes.random_3d_gaussians(10, cam)
+    assert tuple(g.batch_size) == (10,) and g.packed().shape == (10, 11) and len(g.shape_tensors()) == 4
+    assert torch.allclose(g.scale, g.log_scaling.exp()) and torch.allclose(g.alpha, g.alpha_logit.sigmoid())
+    assert g[2:5].position.shape == (3, 3) and tuple(g[2:5].batch_size) == (3,)
+    assert g.concat(g).feature.shape[0] == 20
+    assert g.replace(feature=torch.zeros(10, 3, 16)).feature.shape == (10, 3, 16)
+    assert g.to(dtype=torch.float64).position.dtype == torch.float64
+    g.requires_grad_(True)
+    assert all(t.requires_grad for _, t in g.items())
+    with pytest.raises(AssertionError):
+        Gaussians3D(position=torch.zeros(4, 2), log_scaling=torch.zeros(4, 3), rotation=torch.zeros(4, 4),
+                    alpha_logit=torch.zeros(4, 1), feature=torch.zeros(4, 3), batch_size=(4,))
+    with pytest.raises(RuntimeError):
+        Gaussians3D(position=torch.zeros(4, 3), log_scaling=torch.zeros(5, 3), rotation=torch.zeros(4, 4),
+                    alpha_logit=torch.zeros(4, 1), feature=torch.zeros(4, 3), batch_size=(4,))
+    g2 = scenes.random_2d_gaussians(7, (32, 32))
+    assert isinstance(g2, Gaussians2D) and g2.opacity.shape == (7,) and g2.scaling.shape == (7, 2)
+    assert Gaussians2D.from_tensordict(g2.to_tensordict()).position.shape == (7, 2)
+
+
+def test_camera_params():
+    cam = scenes.benchmark_camera((640, 480))
+    assert cam.depth_range == (0.1, 100.0) and cam.image_size == (640, 480)
+    assert torch.allclose(cam.camera_position, torch.zeros(3))
+    assert cam.T_image_world.shape == (4, 4) and cam.scale_image(0.5).image_size == (320, 240)
+    with pytest.raises(AssertionError):
+        CameraParams(projection=torch.zeros(4), T_camera_world=torch.eye(4), near_plane=0.0, far_plane=1.0,
+                     image_size=(4, 4))
+    with pytest.raises(AssertionError):
+        CameraParams(projection=torch.zeros(3), T_camera_world=torch.eye(4), near_plane=0.1, far_plane=1.0,
+                     image_size=(4, 4))
+
+
+def test_pad_to_tile_and_queue_shim():
+    assert pad_to_tile((257, 131), 16) == (272, 144) and pad_to_tile((32, 32), 16) == (32, 32)
+    with taichi_queue(arch="anything", log_level=0):
+        assert TaichiQueue.run_sync(lambda a, b: a + b, 1, 2) == 3
+        assert TaichiQueue.run_async(lambda: 5).result() == 5
+    TaichiQueue.init(threaded=True)
+    assert queued(lambda x: x * 2)(4) == 8
+    TaichiQueue.stop()
+
+
+def test_operators_refuse_cpu_tensors_loudly():
+    g, cam = scenes.benchmark_scene(50, (64, 64), sh_degree=1)
+    cfg = RasterConfig()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gs.render_gaussians(g, cam, cfg, use_sh=True)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gs.perspective.project_to_image(g, cam, cfg)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gs.evaluate_sh_at(g.feature, g.position, torch.arange(5), torch.zeros(3))
+    g2d = torch.rand(5, 7)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gs.map_to_tiles(g2d, torch.rand(5, 1), (64, 64), cfg)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gs.rasterize_with_tiles(g2d, torch.rand(5, 3), torch.zeros(0, dtype=torch.int32),
+                                torch.zeros((16, 2), dtype=torch.int32), (64, 64), cfg)
+
+
+def test_argument_validation_mirrors_reference():
+    cfg = RasterConfig()
+    with pytest.raises(AssertionError, match="Nx7"):
+        gs.map_to_tiles(torch.rand(5, 6), torch.rand(5, 1), (64, 64), cfg)  # tile_mapper.py:219
+    with pytest.raises(AssertionError, match="Nx1"):
+        gs.map_to_tiles(torch.rand(5, 7), torch.rand(5), (64, 64), cfg)     # tile_mapper.py:220
+    with pytest.raises(TypeError):
+        gs.map_to_tiles(torch.rand(5, 7), torch.rand(5, 1), (64.0, 64), cfg)
+    with pytest.raises(AssertionError, match="Size mismatch"):
+        gs.rasterize(torch.rand(5, 7), torch.rand(4, 1), torch.rand(5, 3), (64, 64), cfg)  # function.py:149
+    with pytest.raises(TypeError):
+        gs.render_gaussians("nope", scenes.benchmark_camera((8, 8)))
+    with pytest.raises(AssertionError, match="square"):
+        gs.evaluate_sh_at(torch.rand(4, 3, 5), torch.rand(4, 3), torch.arange(4), torch.zeros(3))
+
+
+def test_rendering_properties():
+    cam = scenes.benchmark_camera((8, 8))
+    cfg = RasterConfig(compute_visibility=True)
+    r = Rendering(image=torch.zeros(8, 8, 3), image_weight=torch.zeros(8, 8), points_in_view=torch.arange(4),
+                  point_depth=torch.ones(4, 1), point_visibility=torch.tensor([0., 1., 0., 2.]), camera=cam,
+                  config=cfg, gaussians2d=torch.rand(4, 7) + 0.1, depth=torch.ones(8, 8))
+    assert r.num_points == 4 and r.image_size == (8, 8) and r.point_scale.shape == (4, 2)
+    assert r.visible_indices.tolist() == [1, 3] and r.visible[1].tolist() == [1.0, 2.0]
+    assert r.point_radii.shape == (4,) and r.gaussian_scale.shape == (4,) and r.ndc_depth.shape == (8, 8)
+    with pytest.raises(AssertionError):
+        _ = r.prune_cost
+    assert r.detach().image.shape == (8, 8, 3)
+
+
+def test_install_as_taichi_splatting():
+    import sys
+    gs.install_as_taichi_splatting()
+    import taichi_splatting
+    from taichi_splatting.rasterizer import rasterize  # noqa: F401
+    from taichi_splatting.perspective import CameraParams as C2
+    assert taichi_splatting is gs and C2 is CameraParams
+    for k in [k for k in sys.modules if k == "taichi_splatting" or k.startswith("taichi_splatting.")]:
+        del sys.modules[k]

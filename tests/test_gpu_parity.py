@@ -393,3 +393,99 @@ def test_render_gaussians_end_to_end_vs_oracle(seed, n, size, deg, depth_mode):
     for name, key in (("position", "d_position"), ("log_scaling", "d_log_scaling"), ("rotation", "d_rotation"),
                       ("alpha_logit", "d_alpha_logit"), ("feature", "d_feature")):
         pu.assert_rows_close(getattr(gd, name).grad, ref[key], f"grad {name}")
+
+
+# ------------------------------------------------------------------- config 1 on the GPU path
+def test_config1_fit_loop_gpu():
+    """BASELINE config 1 caller shape (examples/fit_image_gaussians.py:101-123) through the HIP
+    operators; first-step loss equals the CPU oracle's for the same seed."""
+    import oracle_ops
+    from test_config1_fit_cpu import fit_loop
+    losses_gpu, raster = fit_loop(gs.rasterize, DEV, steps=8)
+    losses_cpu, _ = fit_loop(oracle_ops.rasterize, "cpu", steps=2)
+    assert abs(losses_gpu[0] - losses_cpu[0]) <= 1e-5 * abs(losses_cpu[0])
+    assert abs(losses_gpu[1] - losses_cpu[1]) <= 1e-3 * abs(losses_cpu[1])
+    assert all(b < a for a, b in zip(losses_gpu, losses_gpu[1:]))
+    assert raster.visibility.shape == (2000,) and raster.point_heuristic.shape == (2000, 2)
+
+
+# ------------------------------------------------------------- tile-strip sharding on one GPU
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_strips_on_one_gpu(world):
+    """the per-rank work of parallel.render_gaussians_sharded, ranks emulated one after another on a
+    single GPU: strips tile the full image, summed partial gradients equal the full gradients"""
+    from taichi_gaussian_rasterizer_amd import parallel
+    size, n = (200, 176), 6000
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=3, seed=4)
+    cam = camera.to(device=DEV)
+    cfg = RasterConfig()
+    gi = dev(torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(9)))
+    full = g.to(DEV).requires_grad_(True)
+    r = gs.render_gaussians(full, cam, cfg, use_sh=True)
+    (r.image * gi).sum().backward()
+    strips, sums = [], None
+    for rank in range(world):
+        gr = g.to(DEV).requires_grad_(True)
+        rr = parallel.render_gaussians_sharded(gr, cam, cfg, use_sh=True, rank=rank, world_size=world)
+        y0, y1 = rr.strip
+        (rr.image * gi[y0:y1]).sum().backward()
+        strips.append(rr.image.detach())
+        grads = {k: v.grad.clone() for k, v in gr.items()}
+        sums = grads if sums is None else {k: sums[k] + grads[k] for k in sums}
+    # without a process group the all-reduce is the identity, so the per-rank gradients are the
+    # partial sums of the replicated backward; projection/SH backward are linear in the upstream grads
+    assert torch.equal(torch.cat(strips, 0), r.image.detach())
+    for k, v in full.items():
+        pu.assert_grad_close(sums[k], v.grad, f"summed partial grad {k}", tol=1e-4)
+
+
+# ------------------------------------------- full-size properties (BASELINE config 3 shapes)
+def test_full_size_c3_properties():
+    """1M Gaussians at 2048x2048, too large for the CPU oracle in a unit test: size-independent
+    properties instead -- sortedness and partition of the mapper output, the visibility identity
+    (tests/test_visibility.py), linearity of the backward in the upstream gradient, determinism of
+    the forward."""
+    n, size = 1_000_000, (2048, 2048)
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=3, seed=0)
+    cam = camera.to(device=DEV)
+    # saturate_threshold = 1: the backward never stops a pixel early, so the visibility identity is
+    # exact up to rounding (at 0.9999 the forward keeps blending a tail the backward drops)
+    cfg = RasterConfig(compute_visibility=True, saturate_threshold=1.0)
+    gd = g.to(DEV)
+    p2d, depth, idx, ndc = hip_proj.project_with_ndc(*gd.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                     cam.image_size, cam.depth_range, cfg)
+    V = p2d.shape[0]
+    assert 0.7 * n < V <= n and bool((idx[1:] > idx[:-1]).all())
+    o2p, ranges, keys = gs.map_to_tiles(p2d, ndc, size, cfg, return_keys=True)
+    K = o2p.shape[0]
+    assert keys.dtype == torch.int64 and bool((keys[1:] >= keys[:-1]).all()), "keys not sorted"
+    same = keys[1:] == keys[:-1]
+    assert bool((o2p[1:][same] > o2p[:-1][same]).all()), "ties not in ascending gaussian order"
+    r = ranges.view(-1, 2).long()
+    nonempty = r[:, 1] > r[:, 0]
+    starts, ends = r[nonempty, 0], r[nonempty, 1]
+    assert int(starts[0]) == 0 and int(ends[-1]) == K and bool((starts[1:] == ends[:-1]).all())
+    assert int(r[~nonempty].abs().sum()) == 0
+    tile_of = (keys >> 32)
+    assert bool((tile_of[starts] == torch.nonzero(nonempty).squeeze(1)).all())
+    # checksum of checksums: every visible gaussian's overlap count equals the reference-shaped count
+    counts = torch.zeros(V, dtype=torch.int64, device=DEV).index_add_(0, o2p.long(), torch.ones(K, dtype=torch.int64, device=DEV))
+    o2p_b, ranges_b = map_to_tiles_reference_stages(p2d, ndc, size, cfg)
+    assert torch.equal(o2p_b, o2p) and torch.equal(ranges_b, ranges)
+    assert int(counts.sum()) == K
+
+    feats = gs.evaluate_sh_at(gd.feature, gd.position, idx, cam.camera_position).requires_grad_(True)
+    p_t = p2d.detach().requires_grad_(True)
+    out = gs.rasterize_with_tiles(p_t, feats, o2p, ranges.view(-1, 2), size, cfg)
+    out2 = gs.rasterize_with_tiles(p2d.detach(), feats.detach(), o2p, ranges.view(-1, 2), size, cfg)
+    assert torch.equal(out.image, out2.image), "forward is not deterministic"
+    assert float(out.image_weight.max()) <= 1.0 + 1e-5 and float(out.image_weight.min()) >= 0.0
+    out.image.sum().backward()
+    vis = out.visibility
+    assert torch.allclose(feats.grad[:, 0], vis, rtol=1e-3, atol=1e-3)
+    g1 = p_t.grad.clone()
+    p_t.grad = None
+    feats.grad = None
+    out = gs.rasterize_with_tiles(p_t, feats, o2p, ranges.view(-1, 2), size, cfg)
+    (out.image.sum() * 2.0).backward()
+    pu.assert_grad_close(p_t.grad, 2.0 * g1, "backward linearity", tol=1e-4)
