@@ -122,16 +122,28 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
     }
     __syncthreads();  // single-wave workgroup: compiles to a wait on the LDS writes, no s_barrier
 
-    // ---- blend
+    // ---- blend.  The next splat's record is fetched from LDS while the current one is blended
+    // (one wave-uniform ds_read burst per splat, its latency hidden behind ~40-90 VALU instructions).
+    float4 n0 = s_geo[0][0], n1 = s_geo[0][1], n2 = make_float4(0, 0, 0, 0);
+    float nfeat[FP];
+#pragma unroll
+    for (int c = 0; c < FP; ++c) nfeat[c] = s_feat[0][c];
+    if (FULL) n2 = s_geo[0][2];
     for (int j = 0; j < cnt; ++j) {
-      const float4 g0v = s_geo[j][0], g1v = s_geo[j][1];
-      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
-      if (mask == 0) continue;
+      const float4 g0v = n0, g1v = n1, g2v = n2;
       float feat[FP];
 #pragma unroll
-      for (int c = 0; c < FP; ++c) feat[c] = s_feat[j][c];
-      float4 g2v = make_float4(0, 0, 0, 0);
-      if (FULL) g2v = s_geo[j][2];
+      for (int c = 0; c < FP; ++c) feat[c] = nfeat[c];
+      {
+        const int jn = j + 1 < cnt ? j + 1 : j;
+        n0 = s_geo[jn][0];
+        n1 = s_geo[jn][1];
+        if (FULL) n2 = s_geo[jn][2];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) nfeat[c] = s_feat[jn][c];
+      }
+      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
+      if (mask == 0) continue;
       float vis_sum = 0.0f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {

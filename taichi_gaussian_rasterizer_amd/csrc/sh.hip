@@ -155,6 +155,75 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int64_t v, int C, const flo
   }
 }
 
+// Dense variant for the renderer: the index list is the projection's visible list, so its inverse
+// (slot_of, N entries, -1 = culled) is known.  One lane per Gaussian writes its whole gradient row --
+// zeros for culled Gaussians -- so the (N,C,D) gradient is produced in a single pass with no memset
+// and no atomics.
+template <int DEG>
+__global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, const float* params,
+                                                           const float* positions, const int* slot_of,
+                                                           const float* cam, const float* gout, int gout_stride,
+                                                           float* d_params, float* d_positions, float* d_cam) {
+  constexpr int D = (DEG + 1) * (DEG + 1);
+  const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  float gd[3] = {0, 0, 0};
+  if (idx < n) {
+    const int slot = slot_of[idx];
+    if (slot < 0) {
+      for (int c = 0; c < C; ++c) {
+        float* drow = d_params + (idx * C + c) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) drow[d] = 0.0f;
+      }
+    } else {
+      const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1],
+                  dz = positions[3 * idx + 2] - cam[2];
+      const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float x = dx / nrm, y = dy / nrm, z = dz / nrm;
+      float Y[D], w[D];
+      rsh<DEG>(x, y, z, Y);
+#pragma unroll
+      for (int d = 0; d < D; ++d) w[d] = 0.0f;
+      for (int c = 0; c < C; ++c) {
+        float row[D];
+        load_row<D>(params + (idx * C + c) * D, row);
+        float acc = 0.0f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc += Y[d] * row[d];
+        const float pre = acc + 0.5f;
+        const float g = (pre >= 0.0f && pre <= 1.0f) ? gout[int64_t(slot) * gout_stride + c] : 0.0f;
+        float* drow = d_params + (idx * C + c) * D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          drow[d] = g * Y[d];
+          w[d] += g * row[d];
+        }
+      }
+      if (DEG >= 1 && (d_positions || d_cam)) {
+        float gdir[3];
+        rsh_grad<DEG>(x, y, z, w, gdir);
+        const float dot = x * gdir[0] + y * gdir[1] + z * gdir[2];
+        gd[0] = (gdir[0] - x * dot) / nrm;
+        gd[1] = (gdir[1] - y * dot) / nrm;
+        gd[2] = (gdir[2] - z * dot) / nrm;
+      }
+    }
+    if (d_positions) { d_positions[3 * idx] = gd[0]; d_positions[3 * idx + 1] = gd[1]; d_positions[3 * idx + 2] = gd[2]; }
+  }
+  if (d_cam && DEG >= 1) {
+    __shared__ float s_part[4][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float tot = gs_wave_sum_to_lane63(gd[k]);
+      if ((threadIdx.x & 63) == 63) s_part[threadIdx.x >> 6][k] = tot;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+      atomicAdd(d_cam + threadIdx.x,
+                -(s_part[0][threadIdx.x] + s_part[1][threadIdx.x] + s_part[2][threadIdx.x] + s_part[3][threadIdx.x]));
+  }
+}
+
 }  // namespace
 
 extern "C" int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
@@ -181,13 +250,36 @@ extern "C" int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const floa
 
 extern "C" int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params,
                          const float* positions, const int64_t* indexes, int32_t indexes_unique,
-                         const float* camera_pos, const float* grad_out, float* d_params, float* d_positions,
-                         float* d_camera_pos, void* stream) {
+                         const int32_t* slot_of, const float* camera_pos, const float* grad_out,
+                         int32_t grad_out_stride, float* d_params, float* d_positions, float* d_camera_pos,
+                         void* stream) {
   GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "gs_sh_bwd: SH degree %d not in [0,3]", degree);
   GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "gs_sh_bwd: %d channels", channels);
   GS_REQUIRE(n == 0 || d_params, GS_ERR_INVALID_ARGUMENT, "gs_sh_bwd: d_params is NULL");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int D = (degree + 1) * (degree + 1);
+  if (grad_out_stride <= 0) grad_out_stride = channels;
+  if (slot_of != nullptr && n > 0) {
+    // dense single pass over all n Gaussians (the renderer's case)
+    GS_REQUIRE(params && positions && camera_pos && grad_out, GS_ERR_INVALID_ARGUMENT, "gs_sh_bwd: NULL buffer");
+    if (d_camera_pos && hipMemsetAsync(d_camera_pos, 0, 12, s) != hipSuccess) {
+      gs_set_error("gs_sh_bwd: hipMemsetAsync failed");
+      return GS_ERR_LAUNCH;
+    }
+    const dim3 grid(unsigned(gs_div_up(n, 256))), block(256);
+#define SH_DENSE(DEG)                                                                                               \
+  hipLaunchKernelGGL((sh_bwd_dense_kernel<DEG>), grid, block, 0, s, n, channels, params, positions, slot_of,        \
+                     camera_pos, grad_out, grad_out_stride, d_params, d_positions, d_camera_pos)
+    switch (degree) {
+      case 0: SH_DENSE(0); break;
+      case 1: SH_DENSE(1); break;
+      case 2: SH_DENSE(2); break;
+      default: SH_DENSE(3); break;
+    }
+    GS_CHECK_LAUNCH("gs_sh_bwd/dense");
+    return GS_OK;
+  }
+  GS_REQUIRE(grad_out_stride == channels, GS_ERR_INVALID_ARGUMENT, "gs_sh_bwd: strided grad_out needs slot_of");
   bool ok = true;
   if (n > 0) ok &= hipMemsetAsync(d_params, 0, size_t(n) * channels * D * 4, s) == hipSuccess;
   if (n > 0 && d_positions) ok &= hipMemsetAsync(d_positions, 0, size_t(n) * 12, s) == hipSuccess;

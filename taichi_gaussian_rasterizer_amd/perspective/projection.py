@@ -56,6 +56,7 @@ class _ProjectFunction(torch.autograd.Function):
         ctx.num_visible = v
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, T, proj, slot_of)
         ctx.mark_non_differentiable(indexes, ndc)
+        ctx.slot_of = slot_of
         return points, depth, indexes, ndc
 
     @staticmethod
@@ -108,6 +109,10 @@ def project_with_ndc(position, log_scaling, rotation, alpha_logit, T_camera_worl
         position.contiguous(), log_scaling.contiguous(), rotation.contiguous(), alpha_logit.contiguous(),
         T_camera_world, projection, image_size, depth_range, config)
     indexes._gs_unique = True  # ascending, no repeats: lets evaluate_sh_at's backward skip atomics
+    node = points.grad_fn
+    slot_of = getattr(node, "slot_of", None) if node is not None else None
+    if slot_of is not None:
+        indexes._gs_slot_of = slot_of  # inverse map: evaluate_sh_at's backward becomes one dense pass
     return points, depth, indexes, ndc
 
 

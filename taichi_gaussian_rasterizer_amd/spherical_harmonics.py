@@ -24,7 +24,7 @@ def check_sh_degree(sh_features):
 
 class _SHFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, params, points, indexes, camera_pos, degree, unique):
+    def forward(ctx, params, points, indexes, camera_pos, degree, unique, slot_of):
         nv.require_device(params, points, camera_pos, what="evaluate_sh_at")
         nv.require_device(indexes, dtype=torch.int64, what="evaluate_sh_at indexes")
         lib = nv.lib()
@@ -33,7 +33,7 @@ class _SHFunction(torch.autograd.Function):
         nv.check(lib.gs_sh_fwd(v, C, degree, nv.ptr(params), nv.ptr(points), nv.ptr(indexes), nv.ptr(camera_pos),
                                nv.ptr(out), nv.stream()), "gs_sh_fwd")
         ctx.save_for_backward(params, points, indexes, camera_pos)
-        ctx.degree, ctx.unique = degree, unique
+        ctx.degree, ctx.unique, ctx.slot_of = degree, unique, slot_of
         return out
 
     @staticmethod
@@ -48,9 +48,9 @@ class _SHFunction(torch.autograd.Function):
         go = doutput.contiguous()
         nv.require_device(go, what="evaluate_sh_at backward")
         nv.check(lib.gs_sh_bwd(n, indexes.shape[0], C, ctx.degree, nv.ptr(params), nv.ptr(points), nv.ptr(indexes),
-                               int(ctx.unique), nv.ptr(camera_pos), nv.ptr(go), nv.ptr(d_params), nv.ptr(d_points),
-                               nv.ptr(d_cam), nv.stream()), "gs_sh_bwd")
-        return d_params, d_points, None, d_cam, None, None
+                               int(ctx.unique), nv.ptr(ctx.slot_of), nv.ptr(camera_pos), nv.ptr(go), C,
+                               nv.ptr(d_params), nv.ptr(d_points), nv.ptr(d_cam), nv.stream()), "gs_sh_bwd")
+        return d_params, d_points, None, d_cam, None, None, None
 
 
 def evaluate_sh_at(sh_params: torch.Tensor,   # M, K, (degree + 1)^2  (usually K=3, for RGB)
@@ -65,5 +65,8 @@ def evaluate_sh_at(sh_params: torch.Tensor,   # M, K, (degree + 1)^2  (usually K
     degree = check_sh_degree(sh_params)
     assert 0 <= degree <= 3, f"SH degree must be between 0 and 3, got {degree}"
     unique = bool(getattr(indexes, "_gs_unique", False))
+    slot_of = getattr(indexes, "_gs_slot_of", None)  # inverse of the projection's visible list
+    if slot_of is not None and slot_of.shape[0] != sh_params.shape[0]:
+        slot_of = None
     return _SHFunction.apply(sh_params.contiguous(), positions.contiguous(), indexes.contiguous(),
-                             camera_pos.contiguous(), degree, unique)
+                             camera_pos.contiguous(), degree, unique, slot_of)
