@@ -155,6 +155,209 @@ __global__ __launch_bounds__(256) void map_emit_kernel(MapArgs a, int* cursors, 
       }
 }
 
+// ---- region-binned counting / bucketing --------------------------------------------------
+// Scattered 4-byte global atomics run at only ~20 G/s on MI355X (every one is its own 64-B
+// memory-side request), which made the plain count / emit kernels above atomic-bound (K atomics
+// each).  The binned path first orders the Gaussians by the screen REGION of their centre (a region
+// is RG x RG tiles; a handful of regions, so the binning itself needs only a few atomics per
+// workgroup), then lets every workgroup -- whose 256 Gaussians now share one region -- count its
+// overlaps in an LDS window covering the region plus a border, and touch global memory once per
+// window tile with row-contiguous (coalescing) atomics: ~12x fewer atomic requests.
+constexpr int RG = 32;                 // region edge in tiles
+constexpr int RB = 4;                  // window border in tiles (splats reaching further fall back to global atomics)
+constexpr int WIN = RG + 2 * RB;       // window edge
+constexpr int WIN_TILES = WIN * WIN;   // 1600 ints = 6.4 KB of LDS
+constexpr int MAX_REGIONS = 1024;
+
+struct RegionGrid {
+  int tiles_x, tiles_y, regions_x, num_regions;
+};
+
+__device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs& a, const RegionGrid& rg) {
+  const float ts = float(a.tile_size);
+  int tx = int(floorf(g[0] / ts)), ty = int(floorf(g[1] / ts));
+  tx = min(max(tx, 0), rg.tiles_x - 1);
+  ty = min(max(ty, 0), rg.tiles_y - 1);
+  return (ty / RG) * rg.regions_x + (tx / RG);
+}
+
+// K1: per-region population.  LDS histogram per workgroup, one global atomic per non-empty bin.
+__global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid rg, int* region_of, int* region_count) {
+  __shared__ int s_hist[MAX_REGIONS];
+  for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_hist[r] = 0;
+  __syncthreads();
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i < a.v) {
+    const int r = region_of_gaussian(a.points + 7 * i, a, rg);
+    region_of[i] = r;
+    atomicAdd(&s_hist[r], 1);
+  }
+  __syncthreads();
+  for (int r = threadIdx.x; r < rg.num_regions; r += 256)
+    if (s_hist[r] > 0) atomicAdd(region_count + r, s_hist[r]);
+}
+
+// K2: exclusive scan of the region populations -> start of each region in the ordered list, and of
+// the per-region chunk counts (a chunk = up to 256 Gaussians of ONE region = one workgroup later on).
+__global__ __launch_bounds__(64) void region_scan_kernel(int num_regions, const int* region_count, int* region_start,
+                                                         int* region_cursor, int* chunk_start) {
+  if (threadIdx.x == 0) {
+    int acc = 0, chunks = 0;
+    for (int r = 0; r < num_regions; ++r) {
+      region_start[r] = acc;
+      region_cursor[r] = acc;
+      chunk_start[r] = chunks;
+      acc += region_count[r];
+      chunks += (region_count[r] + 255) >> 8;
+    }
+    region_start[num_regions] = acc;
+    chunk_start[num_regions] = chunks;
+  }
+}
+
+// K3: write the Gaussian indices grouped by region (order inside a region is irrelevant: the final
+// per-tile sort is on (depth, index)).
+__global__ __launch_bounds__(256) void region_scatter_kernel(MapArgs a, RegionGrid rg, const int* region_of,
+                                                             int* region_cursor, int* order) {
+  __shared__ int s_cnt[MAX_REGIONS];
+  __shared__ int s_base[MAX_REGIONS];
+  for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_cnt[r] = 0;
+  __syncthreads();
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  int r = 0, local = 0;
+  if (i < a.v) {
+    r = region_of[i];
+    local = atomicAdd(&s_cnt[r], 1);
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < rg.num_regions; q += 256)
+    if (s_cnt[q] > 0) s_base[q] = atomicAdd(region_cursor + q, s_cnt[q]);
+  __syncthreads();
+  if (i < a.v) order[s_base[r] + local] = int(i);
+}
+
+// which chunk of which region does this workgroup process?
+__device__ __forceinline__ bool locate_chunk(int block, const RegionGrid& rg, const int* region_start,
+                                             const int* chunk_start, int& region, int& first, int& count) {
+  __shared__ int s_loc[3];
+  if (threadIdx.x == 0) {
+    int r = -1;
+    if (block < chunk_start[rg.num_regions]) {
+      int lo = 0, hi = rg.num_regions;  // last r with chunk_start[r] <= block
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (chunk_start[mid] <= block) lo = mid; else hi = mid;
+      }
+      r = lo;
+      const int c = block - chunk_start[r];
+      s_loc[1] = region_start[r] + c * 256;
+      s_loc[2] = min(256, region_start[r + 1] - s_loc[1]);
+    }
+    s_loc[0] = r;
+  }
+  __syncthreads();
+  region = s_loc[0];
+  first = s_loc[1];
+  count = s_loc[2];
+  return region >= 0;
+}
+
+// K4: per-tile histogram through the LDS window.
+__global__ __launch_bounds__(256) void count_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
+                                                           const int* region_start, const int* chunk_start,
+                                                           int* tile_hist) {
+  __shared__ int s_win[WIN_TILES];
+  int region, first, count;
+  if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
+  for (int e = threadIdx.x; e < WIN_TILES; e += 256) s_win[e] = 0;
+  __syncthreads();
+  const int wx0 = (region % rg.regions_x) * RG - RB, wy0 = (region / rg.regions_x) * RG - RB;
+  if (int(threadIdx.x) < count) {
+    const int i = order[first + threadIdx.x];
+    const GridQuery q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
+    for (int ty = 0; ty < q.span_y; ++ty)
+      for (int tx = 0; tx < q.span_x; ++tx)
+        if (test_tile(q, tx, ty, a.tile_size)) {
+          const int gx = tx + q.min_tx, gy = ty + q.min_ty;
+          const int lx = gx - wx0, ly = gy - wy0;
+          if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_win[ly * WIN + lx], 1);
+          else atomicAdd(tile_hist + gx + gy * a.tiles_wide, 1);
+        }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < WIN_TILES; e += 256) {
+    const int c = s_win[e];
+    if (c > 0) {
+      const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
+      atomicAdd(tile_hist + gx + gy * a.tiles_wide, c);
+    }
+  }
+}
+
+// K6: bucket the (depth key, index) pairs.  Pass A counts into the LDS window, pass B reserves one
+// contiguous range per window tile with a single returning global atomic, pass C places the pairs
+// with LDS atomics.  The accepted-tile set of a lane is kept as a 64-bit mask between the passes
+// when its candidate span fits (<= 64 tiles), so the OBB tests run once.
+__global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
+                                                          const int* region_start, const int* chunk_start,
+                                                          int* cursors, uint64_t* pairs) {
+  __shared__ int s_cnt[WIN_TILES];
+  __shared__ int s_base[WIN_TILES];
+  int region, first, count;
+  if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
+  for (int e = threadIdx.x; e < WIN_TILES; e += 256) s_cnt[e] = 0;
+  __syncthreads();
+  const int wx0 = (region % rg.regions_x) * RG - RB, wy0 = (region / rg.regions_x) * RG - RB;
+  const bool active = int(threadIdx.x) < count;
+  GridQuery q;
+  q.span_x = q.span_y = 0;
+  uint64_t accept = 0ull;
+  bool masked = false;
+  int i = 0;
+  if (active) {
+    i = order[first + threadIdx.x];
+    q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
+    masked = q.span_x * q.span_y <= 64;
+    int bit = 0;
+    for (int ty = 0; ty < q.span_y; ++ty)
+      for (int tx = 0; tx < q.span_x; ++tx, ++bit)
+        if (test_tile(q, tx, ty, a.tile_size)) {
+          if (masked) accept |= 1ull << bit;
+          const int lx = tx + q.min_tx - wx0, ly = ty + q.min_ty - wy0;
+          if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
+        }
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < WIN_TILES; e += 256) {
+    const int c = s_cnt[e];
+    if (c > 0) {
+      const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
+      s_base[e] = atomicAdd(cursors + gx + gy * a.tiles_wide, c);
+    }
+    s_cnt[e] = 0;
+  }
+  __syncthreads();
+  if (active) {
+    const uint64_t pair = (uint64_t(depth_key(a.depth[i], a.depth16 != 0)) << 32) | uint64_t(uint32_t(i));
+    int bit = 0;
+    for (int ty = 0; ty < q.span_y; ++ty)
+      for (int tx = 0; tx < q.span_x; ++tx, ++bit) {
+        const bool hit = masked ? ((accept >> bit) & 1ull) != 0ull : test_tile(q, tx, ty, a.tile_size);
+        if (!hit) continue;
+        const int gx = tx + q.min_tx, gy = ty + q.min_ty;
+        const int lx = gx - wx0, ly = gy - wy0;
+        int slot;
+        if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) {
+          const int e = ly * WIN + lx;
+          slot = s_base[e] + atomicAdd(&s_cnt[e], 1);
+        } else {
+          slot = atomicAdd(cursors + gx + gy * a.tiles_wide, 1);
+        }
+        pairs[slot] = pair;
+      }
+  }
+}
+
 // One workgroup per tile.  n <= CAP: bitonic sort in LDS.  n > CAP: the same network in place in
 // global memory (rare: more than CAP splats on one tile); a workgroup lives on one CU, so its own
 // global writes are visible to it after __syncthreads().
@@ -385,9 +588,37 @@ int fill_args(MapArgs& a, int64_t v, const float* points, const float* depth, in
 
 }  // namespace
 
+namespace {
+struct MapScratch {
+  int* hist; int* cursors; int* region_of; int* order; int* region_count; int* region_start; int* region_cursor;
+  int* chunk_start;
+};
+MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
+  char* p = static_cast<char*>(scratch);
+  MapScratch m;
+  auto take = [&](int64_t bytes) { int* r = reinterpret_cast<int*>(p); p += gs_align_up(bytes, 256); return r; };
+  m.hist = take(num_tiles * 4);
+  m.cursors = take(num_tiles * 4);
+  m.region_of = take(v * 4);
+  m.order = take(v * 4);
+  m.region_count = take((MAX_REGIONS + 1) * 4);
+  m.region_start = take((MAX_REGIONS + 1) * 4);
+  m.region_cursor = take((MAX_REGIONS + 1) * 4);
+  m.chunk_start = take((MAX_REGIONS + 1) * 4);
+  return m;
+}
+RegionGrid make_grid(const MapArgs& a) {
+  RegionGrid rg;
+  rg.tiles_x = a.tiles_wide;
+  rg.tiles_y = a.Hp / a.tile_size;
+  rg.regions_x = int(gs_div_up(rg.tiles_x, RG));
+  rg.num_regions = rg.regions_x * int(gs_div_up(rg.tiles_y, RG));
+  return rg;
+}
+}  // namespace
+
 extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
-  (void)v;
-  return gs_align_up(num_tiles * 4, 256) * 2;  // histogram + cursors
+  return gs_align_up(num_tiles * 4, 256) * 2 + gs_align_up(v * 4, 256) * 2 + gs_align_up((MAX_REGIONS + 1) * 4, 256) * 4;
 }
 
 extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int32_t height,
@@ -402,15 +633,28 @@ extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int
              (long long)gs_map_scratch_bytes(v, num_tiles));
   GS_REQUIRE(num_tiles <= (1 << 20), GS_ERR_UNSUPPORTED, "gs_map_prepare: %d tiles (limit 2^20)", num_tiles);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* hist = static_cast<int*>(scratch);
-  int* cursors = hist + gs_align_up(int64_t(num_tiles) * 4, 256) / 4;
-  if (hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) != hipSuccess) {
+  const MapScratch m = carve(scratch, v, num_tiles);
+  int* hist = m.hist;
+  int* cursors = m.cursors;
+  const RegionGrid rg = make_grid(a);
+  GS_REQUIRE(rg.num_regions <= MAX_REGIONS, GS_ERR_UNSUPPORTED, "gs_map_prepare: %d regions", rg.num_regions);
+  bool ok = hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) == hipSuccess;
+  ok &= hipMemsetAsync(m.region_count, 0, size_t(rg.num_regions + 1) * 4, s) == hipSuccess;
+  if (!ok) {
     gs_set_error("gs_map_prepare: hipMemsetAsync failed");
     return GS_ERR_LAUNCH;
   }
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
-    hipLaunchKernelGGL(map_count_kernel, dim3(unsigned(gs_div_up(v, 256))), dim3(256), 0, s, a, hist);
+    const unsigned vb = unsigned(gs_div_up(v, 256));
+    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(256), 0, s, a, rg, m.region_of, m.region_count);
+    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(64), 0, s, rg.num_regions, m.region_count, m.region_start,
+                       m.region_cursor, m.chunk_start);
+    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(256), 0, s, a, rg, m.region_of, m.region_cursor,
+                       m.order);
+    // one workgroup per chunk of <= 256 Gaussians of one region; surplus workgroups exit at once
+    hipLaunchKernelGGL(count_binned_kernel, dim3(vb + unsigned(rg.num_regions)), dim3(256), 0, s, a, rg, m.order,
+                       m.region_start, m.chunk_start, hist);
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
   hipLaunchKernelGGL(map_scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist,
@@ -432,9 +676,13 @@ extern "C" int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const
   GS_REQUIRE(scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
              "gs_map_finish: scratch too small");
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* cursors = static_cast<int*>(scratch) + gs_align_up(int64_t(num_tiles) * 4, 256) / 4;
+  const MapScratch m = carve(scratch, v, num_tiles);
+  int* cursors = m.cursors;
+  const RegionGrid rg = make_grid(a);
   uint64_t* pairs = static_cast<uint64_t*>(pair_scratch);
-  hipLaunchKernelGGL(map_emit_kernel, dim3(unsigned(gs_div_up(v, 256))), dim3(256), 0, s, a, cursors, pairs);
+  // the region ordering left in scratch by gs_map_prepare is reused here
+  hipLaunchKernelGGL(emit_binned_kernel, dim3(unsigned(gs_div_up(v, 256)) + unsigned(rg.num_regions)), dim3(256), 0, s,
+                     a, rg, m.order, m.region_start, m.chunk_start, cursors, pairs);
   GS_CHECK_LAUNCH("gs_map_finish/emit");
   const int grid = 8 * int(gs_div_up(num_tiles, 8));
   const int2* r = reinterpret_cast<const int2*>(tile_ranges);
