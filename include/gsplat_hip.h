@@ -104,14 +104,16 @@ int gs_project_bwd(int64_t n, int64_t v, const float* position, const float* log
  * be NULL.  If slot_of (n int32: row of Gaussian i in the index list, or -1; from gs_project_fwd)
  * is given, the dense gradient is written in one pass over all n Gaussians (no memset, no atomics) and
  * grad_out may be strided: row i of the upstream gradient is grad_out + i*grad_out_stride
- * (grad_out_stride <= 0 means `channels`).
+ * (grad_out_stride <= 0 means `channels`).  fwd_out (optional, same striding rule) is the forward's
+ * output: when given and neither d_positions nor d_camera_pos is requested, the clamp mask is taken
+ * from it (0 < out < 1) and the coefficients are not re-read.
  */
 int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, const float* camera_pos, float* out, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
-              const float* grad_out, int32_t grad_out_stride, float* d_params, float* d_positions,
-              float* d_camera_pos, void* stream);
+              const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,
+              float* d_params, float* d_positions, float* d_camera_pos, void* stream);
 
 /* --------------------------------------------------------------- tile mapper (a5 - a10) --
  * Fused path (what map_to_tiles runs).  replaces mapper/tile_mapper.py:169-196 as a whole:

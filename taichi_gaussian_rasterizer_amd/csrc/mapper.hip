@@ -8,11 +8,14 @@
 //
 // Fused path (gs_map_prepare / gs_map_finish), designed for MI355X rather than around a
 // library radix sort:
-//   count   : 1 lane per Gaussian, OBB query, one no-return int atomic per accepted tile into a
-//             T-entry histogram (T <= 65536 words: L2-resident).
+//   bin     : order the Gaussians by the screen region (32x32 tiles) of their centre -- LDS
+//             histograms + a per-region scan over workgroups, no global atomics.
+//   count   : 1 lane per Gaussian, OBB query; overlaps are counted in an LDS window over the
+//             workgroup's region (+ border) and flushed with row-contiguous atomics into a T-entry
+//             histogram (scattered 4-B global atomics only reach ~20 G/s on MI355X).
 //   scan    : single workgroup exclusive scan of the histogram -> tile_ranges, cursors, K, max.
-//   emit    : the query again; slot = returning atomic on the tile's cursor; writes the 64-bit
-//             composite (depth key << 32 | gaussian index) into the tile's bucket.
+//   emit    : the query again; one returning atomic per (workgroup, tile) reserves a range of the
+//             tile's bucket, LDS atomics place the 64-bit composites (depth key << 32 | index).
 //   sort    : one wave per tile rank-sorts its bucket (bitonic in LDS / global for crowded tiles).
 //             The composite makes the result independent of the atomic arrival order and equal
 //             to the reference's stable radix sort of (tile << 32 | depth) in generation order.
@@ -100,16 +103,6 @@ struct MapArgs {
 };
 
 // ---- fused path -------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void map_count_kernel(MapArgs a, int* tile_hist) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.v) return;
-  const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
-  for (int ty = 0; ty < q.span_y; ++ty)
-    for (int tx = 0; tx < q.span_x; ++tx)
-      if (test_tile(q, tx, ty, a.tile_size))
-        atomicAdd(tile_hist + (tx + q.min_tx) + (ty + q.min_ty) * a.tiles_wide, 1);
-}
-
 // single-workgroup exclusive scan over the T-entry histogram (T <= 65536 + slack)
 __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
                                                         int* cursors, int* counts_out) {
@@ -141,20 +134,6 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   if (t == 1023) { counts_out[0] = s_part[1023]; counts_out[1] = s_max[1023]; }
 }
 
-__global__ __launch_bounds__(256) void map_emit_kernel(MapArgs a, int* cursors, uint64_t* pairs) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.v) return;
-  const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
-  if (q.span_x == 0 || q.span_y == 0) return;
-  const uint64_t pair = (uint64_t(depth_key(a.depth[i], a.depth16 != 0)) << 32) | uint64_t(uint32_t(i));
-  for (int ty = 0; ty < q.span_y; ++ty)
-    for (int tx = 0; tx < q.span_x; ++tx)
-      if (test_tile(q, tx, ty, a.tile_size)) {
-        const int slot = atomicAdd(cursors + (tx + q.min_tx) + (ty + q.min_ty) * a.tiles_wide, 1);
-        pairs[slot] = pair;
-      }
-}
-
 // ---- region-binned counting / bucketing --------------------------------------------------
 // Scattered 4-byte global atomics run at only ~20 G/s on MI355X (every one is its own 64-B
 // memory-side request), which made the plain count / emit kernels above atomic-bound (K atomics
@@ -181,8 +160,10 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
   return (ty / RG) * rg.regions_x + (tx / RG);
 }
 
-// K1: per-region population.  LDS histogram per workgroup, one global atomic per non-empty bin.
-__global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid rg, int* region_of, int* region_count) {
+// K1: per-workgroup region populations, written to part[region][workgroup] (no global atomics:
+// thousands of workgroups adding into a handful of counters would serialise on one line).
+__global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
+                                                           int* part) {
   __shared__ int s_hist[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_hist[r] = 0;
   __syncthreads();
@@ -193,19 +174,44 @@ __global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid
     atomicAdd(&s_hist[r], 1);
   }
   __syncthreads();
-  for (int r = threadIdx.x; r < rg.num_regions; r += 256)
-    if (s_hist[r] > 0) atomicAdd(region_count + r, s_hist[r]);
+  for (int r = threadIdx.x; r < rg.num_regions; r += 256) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
 }
 
-// K2: exclusive scan of the region populations -> start of each region in the ordered list, and of
+// K2a: one workgroup per region: exclusive scan of part[region][*] in place, total -> region_count.
+__global__ __launch_bounds__(256) void region_part_scan_kernel(int num_wg, int* part, int* region_count) {
+  __shared__ int s[256];
+  __shared__ int carry;
+  int* row = part + int64_t(blockIdx.x) * num_wg;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < num_wg; base += 256) {
+    const int i = base + threadIdx.x;
+    const int v = i < num_wg ? row[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      int x = s[threadIdx.x];
+      if (threadIdx.x >= off) x += s[threadIdx.x - off];
+      __syncthreads();
+      s[threadIdx.x] = x;
+      __syncthreads();
+    }
+    if (i < num_wg) row[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 255) carry += s[255];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) region_count[blockIdx.x] = carry;
+}
+
+// K2b: exclusive scan of the region populations -> start of each region in the ordered list, and of
 // the per-region chunk counts (a chunk = up to 256 Gaussians of ONE region = one workgroup later on).
 __global__ __launch_bounds__(64) void region_scan_kernel(int num_regions, const int* region_count, int* region_start,
-                                                         int* region_cursor, int* chunk_start) {
+                                                         int* chunk_start) {
   if (threadIdx.x == 0) {
     int acc = 0, chunks = 0;
     for (int r = 0; r < num_regions; ++r) {
       region_start[r] = acc;
-      region_cursor[r] = acc;
       chunk_start[r] = chunks;
       acc += region_count[r];
       chunks += (region_count[r] + 255) >> 8;
@@ -215,25 +221,19 @@ __global__ __launch_bounds__(64) void region_scan_kernel(int num_regions, const 
   }
 }
 
-// K3: write the Gaussian indices grouped by region (order inside a region is irrelevant: the final
-// per-tile sort is on (depth, index)).
-__global__ __launch_bounds__(256) void region_scatter_kernel(MapArgs a, RegionGrid rg, const int* region_of,
-                                                             int* region_cursor, int* order) {
+// K3: write the Gaussian indices grouped by region: position = region start + this workgroup's
+// offset inside the region (K2a) + rank inside the workgroup (LDS atomic).
+__global__ __launch_bounds__(256) void region_scatter_kernel(MapArgs a, RegionGrid rg, int num_wg, const int* region_of,
+                                                             const int* part, const int* region_start, int* order) {
   __shared__ int s_cnt[MAX_REGIONS];
-  __shared__ int s_base[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_cnt[r] = 0;
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  int r = 0, local = 0;
   if (i < a.v) {
-    r = region_of[i];
-    local = atomicAdd(&s_cnt[r], 1);
+    const int r = region_of[i];
+    const int local = atomicAdd(&s_cnt[r], 1);
+    order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = int(i);
   }
-  __syncthreads();
-  for (int q = threadIdx.x; q < rg.num_regions; q += 256)
-    if (s_cnt[q] > 0) s_base[q] = atomicAdd(region_cursor + q, s_cnt[q]);
-  __syncthreads();
-  if (i < a.v) order[s_base[r] + local] = int(i);
 }
 
 // which chunk of which region does this workgroup process?
@@ -424,10 +424,38 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const
 // count.  n^2/64 compares per tile, no barriers, no data-dependent control flow; ~5x faster than
 // the LDS bitonic network at these sizes.
 template <int R>
+__device__ __forceinline__ void rank_sort_rows(const uint64_t* s_key, const uint64_t* seg, int n, int lane, int start,
+                                               int tile, int* o2p, uint64_t* keys_out, int shift) {
+  uint64_t mine[R];
+  int rank[R];
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    const int i = q * 64 + lane;
+    mine[q] = i < n ? s_key[i] : ~0ull;
+    rank[q] = 0;
+  }
+  for (int j = 0; j < n; ++j) {
+    const uint64_t kj = s_key[j];
+#pragma unroll
+    for (int q = 0; q < R; ++q) rank[q] += kj < mine[q] ? 1 : 0;
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q) {
+    if (q * 64 + lane < n) {
+      o2p[start + rank[q]] = int(uint32_t(mine[q]));
+      if (keys_out) keys_out[start + rank[q]] = (mine[q] >> 32) | (uint64_t(uint32_t(tile)) << shift);
+    }
+  }
+}
+
+// RMAX bounds the LDS buffer (64*RMAX keys); the number of register rows is chosen PER TILE from its
+// own population, so a 100-splat tile in a frame whose fullest tile holds 500 does 2 rows of
+// compares, not 8.
+template <int RMAX>
 __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const int2* tile_ranges,
                                                             const uint64_t* pairs, int* o2p, uint64_t* keys_out,
                                                             int depth16) {
-  __shared__ uint64_t s_key[64 * R];
+  __shared__ uint64_t s_key[64 * RMAX];
   const int tile = gs_xcd_remap(blockIdx.x, num_tiles);
   if (tile < 0) return;
   const int2 r = tile_ranges[tile];
@@ -435,29 +463,14 @@ __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const
   if (n <= 0) return;
   const uint64_t* seg = pairs + r.x;
   const int lane = threadIdx.x;
-  uint64_t mine[R];
-  int rank[R];
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    const int i = q * 64 + lane;
-    mine[q] = i < n ? seg[i] : ~0ull;
-    rank[q] = 0;
-    if (i < n) s_key[i] = mine[q];
-  }
+  for (int i = lane; i < n; i += 64) s_key[i] = seg[i];
   __syncthreads();
-  for (int j = 0; j < n; ++j) {
-    const uint64_t kj = s_key[j];
-#pragma unroll
-    for (int q = 0; q < R; ++q) rank[q] += kj < mine[q] ? 1 : 0;
-  }
   const int shift = depth16 ? 16 : 32;
-#pragma unroll
-  for (int q = 0; q < R; ++q) {
-    if (q * 64 + lane < n) {
-      o2p[r.x + rank[q]] = int(uint32_t(mine[q]));
-      if (keys_out) keys_out[r.x + rank[q]] = (mine[q] >> 32) | (uint64_t(uint32_t(tile)) << shift);
-    }
-  }
+  if (n <= 64) rank_sort_rows<1>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (n <= 128) rank_sort_rows<2>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (n <= 256) rank_sort_rows<4>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (RMAX >= 8 && n <= 512) rank_sort_rows<(RMAX >= 8 ? 8 : 4)>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (RMAX >= 16) rank_sort_rows<(RMAX >= 16 ? 16 : 4)>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
 }
 
 // ---- reference-shaped primitives ----------------------------------------------------------
@@ -590,9 +603,15 @@ int fill_args(MapArgs& a, int64_t v, const float* points, const float* depth, in
 
 namespace {
 struct MapScratch {
-  int* hist; int* cursors; int* region_of; int* order; int* region_count; int* region_start; int* region_cursor;
+  int* hist; int* cursors; int* region_of; int* order; int* region_count; int* region_start; int* part;
   int* chunk_start;
 };
+// part[region][workgroup]; the region count is bounded by the tile count (RG x RG tiles per region,
+// at least one region per RG tiles along each axis)
+int64_t part_entries(int64_t v, int64_t num_tiles) {
+  const int64_t regions = num_tiles < MAX_REGIONS ? (num_tiles < 1 ? 1 : num_tiles) : MAX_REGIONS;
+  return regions * gs_div_up(v > 0 ? v : 1, 256);
+}
 MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
   char* p = static_cast<char*>(scratch);
   MapScratch m;
@@ -603,8 +622,8 @@ MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
   m.order = take(v * 4);
   m.region_count = take((MAX_REGIONS + 1) * 4);
   m.region_start = take((MAX_REGIONS + 1) * 4);
-  m.region_cursor = take((MAX_REGIONS + 1) * 4);
   m.chunk_start = take((MAX_REGIONS + 1) * 4);
+  m.part = take(part_entries(v, num_tiles) * 4);
   return m;
 }
 RegionGrid make_grid(const MapArgs& a) {
@@ -618,7 +637,8 @@ RegionGrid make_grid(const MapArgs& a) {
 }  // namespace
 
 extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
-  return gs_align_up(num_tiles * 4, 256) * 2 + gs_align_up(v * 4, 256) * 2 + gs_align_up((MAX_REGIONS + 1) * 4, 256) * 4;
+  return gs_align_up(num_tiles * 4, 256) * 2 + gs_align_up(v * 4, 256) * 2 +
+         gs_align_up((MAX_REGIONS + 1) * 4, 256) * 3 + gs_align_up(part_entries(v, num_tiles) * 4, 256);
 }
 
 extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int32_t height,
@@ -638,8 +658,7 @@ extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int
   int* cursors = m.cursors;
   const RegionGrid rg = make_grid(a);
   GS_REQUIRE(rg.num_regions <= MAX_REGIONS, GS_ERR_UNSUPPORTED, "gs_map_prepare: %d regions", rg.num_regions);
-  bool ok = hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) == hipSuccess;
-  ok &= hipMemsetAsync(m.region_count, 0, size_t(rg.num_regions + 1) * 4, s) == hipSuccess;
+  const bool ok = hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) == hipSuccess;
   if (!ok) {
     gs_set_error("gs_map_prepare: hipMemsetAsync failed");
     return GS_ERR_LAUNCH;
@@ -647,11 +666,13 @@ extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
     const unsigned vb = unsigned(gs_div_up(v, 256));
-    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(256), 0, s, a, rg, m.region_of, m.region_count);
+    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part);
+    hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(256), 0, s, int(vb), m.part,
+                       m.region_count);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(64), 0, s, rg.num_regions, m.region_count, m.region_start,
-                       m.region_cursor, m.chunk_start);
-    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(256), 0, s, a, rg, m.region_of, m.region_cursor,
-                       m.order);
+                       m.chunk_start);
+    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part,
+                       m.region_start, m.order);
     // one workgroup per chunk of <= 256 Gaussians of one region; surplus workgroups exit at once
     hipLaunchKernelGGL(count_binned_kernel, dim3(vb + unsigned(rg.num_regions)), dim3(256), 0, s, a, rg, m.order,
                        m.region_start, m.chunk_start, hist);

@@ -163,6 +163,7 @@ template <int DEG>
 __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, const float* params,
                                                            const float* positions, const int* slot_of,
                                                            const float* cam, const float* gout, int gout_stride,
+                                                           const float* fwd_out, int fwd_out_stride,
                                                            float* d_params, float* d_positions, float* d_cam) {
   constexpr int D = (DEG + 1) * (DEG + 1);
   const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -172,8 +173,14 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
     if (slot < 0) {
       for (int c = 0; c < C; ++c) {
         float* drow = d_params + (idx * C + c) * D;
+        if ((D & 3) == 0) {
+          float4* d4 = reinterpret_cast<float4*>(drow);
 #pragma unroll
-        for (int d = 0; d < D; ++d) drow[d] = 0.0f;
+          for (int k = 0; k < D / 4; ++k) d4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+#pragma unroll
+          for (int d = 0; d < D; ++d) drow[d] = 0.0f;
+        }
       }
     } else {
       const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1],
@@ -184,19 +191,34 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
       rsh<DEG>(x, y, z, Y);
 #pragma unroll
       for (int d = 0; d < D; ++d) w[d] = 0.0f;
+      const bool need_dir = d_positions != nullptr || d_cam != nullptr;
       for (int c = 0; c < C; ++c) {
         float row[D];
-        load_row<D>(params + (idx * C + c) * D, row);
-        float acc = 0.0f;
+        float g = gout[int64_t(slot) * gout_stride + c];
+        if (fwd_out != nullptr && !need_dir) {
+          // the forward's clamped output tells whether the clamp was active: no need to re-read the
+          // (N,C,D) coefficients just to recompute it (halves the HBM traffic of this kernel)
+          const float o = fwd_out[int64_t(slot) * fwd_out_stride + c];
+          if (!(o > 0.0f && o < 1.0f)) g = 0.0f;
+        } else {
+          load_row<D>(params + (idx * C + c) * D, row);
+          float acc = 0.0f;
 #pragma unroll
-        for (int d = 0; d < D; ++d) acc += Y[d] * row[d];
-        const float pre = acc + 0.5f;
-        const float g = (pre >= 0.0f && pre <= 1.0f) ? gout[int64_t(slot) * gout_stride + c] : 0.0f;
+          for (int d = 0; d < D; ++d) acc += Y[d] * row[d];
+          const float pre = acc + 0.5f;
+          if (!(pre >= 0.0f && pre <= 1.0f)) g = 0.0f;
+#pragma unroll
+          for (int d = 0; d < D; ++d) w[d] += g * row[d];
+        }
         float* drow = d_params + (idx * C + c) * D;
+        if ((D & 3) == 0) {
+          float4* d4 = reinterpret_cast<float4*>(drow);
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-          drow[d] = g * Y[d];
-          w[d] += g * row[d];
+          for (int k = 0; k < D / 4; ++k)
+            d4[k] = make_float4(g * Y[4 * k], g * Y[4 * k + 1], g * Y[4 * k + 2], g * Y[4 * k + 3]);
+        } else {
+#pragma unroll
+          for (int d = 0; d < D; ++d) drow[d] = g * Y[d];
         }
       }
       if (DEG >= 1 && (d_positions || d_cam)) {
@@ -251,8 +273,8 @@ extern "C" int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const floa
 extern "C" int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params,
                          const float* positions, const int64_t* indexes, int32_t indexes_unique,
                          const int32_t* slot_of, const float* camera_pos, const float* grad_out,
-                         int32_t grad_out_stride, float* d_params, float* d_positions, float* d_camera_pos,
-                         void* stream) {
+                         int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride, float* d_params,
+                         float* d_positions, float* d_camera_pos, void* stream) {
   GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "gs_sh_bwd: SH degree %d not in [0,3]", degree);
   GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "gs_sh_bwd: %d channels", channels);
   GS_REQUIRE(n == 0 || d_params, GS_ERR_INVALID_ARGUMENT, "gs_sh_bwd: d_params is NULL");
@@ -269,7 +291,8 @@ extern "C" int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree,
     const dim3 grid(unsigned(gs_div_up(n, 256))), block(256);
 #define SH_DENSE(DEG)                                                                                               \
   hipLaunchKernelGGL((sh_bwd_dense_kernel<DEG>), grid, block, 0, s, n, channels, params, positions, slot_of,        \
-                     camera_pos, grad_out, grad_out_stride, d_params, d_positions, d_camera_pos)
+                     camera_pos, grad_out, grad_out_stride, fwd_out, fwd_out_stride > 0 ? fwd_out_stride : channels,   \
+                     d_params, d_positions, d_camera_pos)
     switch (degree) {
       case 0: SH_DENSE(0); break;
       case 1: SH_DENSE(1); break;

@@ -32,13 +32,13 @@ class _SHFunction(torch.autograd.Function):
         out = torch.empty((v, C), dtype=torch.float32, device=params.device)
         nv.check(lib.gs_sh_fwd(v, C, degree, nv.ptr(params), nv.ptr(points), nv.ptr(indexes), nv.ptr(camera_pos),
                                nv.ptr(out), nv.stream()), "gs_sh_fwd")
-        ctx.save_for_backward(params, points, indexes, camera_pos)
+        ctx.save_for_backward(params, points, indexes, camera_pos, out)
         ctx.degree, ctx.unique, ctx.slot_of = degree, unique, slot_of
         return out
 
     @staticmethod
     def backward(ctx, doutput):
-        params, points, indexes, camera_pos = ctx.saved_tensors
+        params, points, indexes, camera_pos, out = ctx.saved_tensors
         lib = nv.lib()
         n, C = params.shape[0], params.shape[1]
         need_pts, need_cam = ctx.needs_input_grad[1], ctx.needs_input_grad[3]
@@ -49,7 +49,8 @@ class _SHFunction(torch.autograd.Function):
         nv.require_device(go, what="evaluate_sh_at backward")
         nv.check(lib.gs_sh_bwd(n, indexes.shape[0], C, ctx.degree, nv.ptr(params), nv.ptr(points), nv.ptr(indexes),
                                int(ctx.unique), nv.ptr(ctx.slot_of), nv.ptr(camera_pos), nv.ptr(go), C,
-                               nv.ptr(d_params), nv.ptr(d_points), nv.ptr(d_cam), nv.stream()), "gs_sh_bwd")
+                               nv.ptr(out), C, nv.ptr(d_params), nv.ptr(d_points), nv.ptr(d_cam), nv.stream()),
+                 "gs_sh_bwd")
         return d_params, d_points, None, d_cam, None, None, None
 
 
