@@ -68,6 +68,8 @@ int gs_version(void);
  *   points: (V,7) [mean.xy, axis.xy, sigma.xy, alpha]; depth: (V) camera z; ndc_depth: (V)
  *   = 1 - (1/z - (float)(1/far)) / (float)(1/near - 1/far)  (fixed f32 op order);
  *   indexes: (V) int64 ascending; slot_of: (n) int32, compact row of Gaussian i or -1.
+ *   depth_features (optional): row i of a (V, depth_features_stride) raster-feature buffer receives
+ *   [z, z^2] in its first two columns (renderer.py:191-193, render_depth=True).
  * scratch: gs_project_scratch_bytes(n).
  */
 int64_t gs_project_scratch_bytes(int64_t n);
@@ -75,13 +77,16 @@ int gs_project_fwd(int64_t n, const float* position, const float* log_scaling, c
                    const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
                    int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
                    float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
-                   void* scratch, int64_t scratch_bytes, void* stream);
+                   float* depth_features, int32_t depth_features_stride, void* scratch, int64_t scratch_bytes,
+                   void* stream);
 
 /* replaces: perspective/projection.py:84-118 indexed_project_kernel.grad (Taichi autodiff,
  * :166-185).  Hand-derived adjoint.  Dense gradients (rows of culled Gaussians are zero);
  * d_T_camera_world is 16 floats (last row zero) and d_projection 4 floats, summed over the
  * visible set (the reference sums its per-point expanded copies, :212-213).  Either may be NULL.
- * grad_points (V,7), grad_depth (V) may be NULL (treated as zero).
+ * grad_points (row stride grad_points_stride, <= 0 means 7), grad_depth and grad_depth_sq (stride
+ * grad_depth_stride, <= 0 means 1) may be NULL (treated as zero); grad_depth_sq is the gradient of a
+ * z^2 feature and contributes 2 z g (so the rasterizer's gradient rows can be consumed in place).
  * scratch: gs_project_bwd_scratch_bytes(n) (per-block camera partials; unused when both camera
  * outputs are NULL).
  */
@@ -89,14 +94,20 @@ int64_t gs_project_bwd_scratch_bytes(int64_t n);
 int gs_project_bwd(int64_t n, int64_t v, const float* position, const float* log_scaling, const float* rotation,
                    const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
                    int32_t height, const GsRasterConfig* cfg, const int32_t* slot_of, const float* grad_points,
-                   const float* grad_depth, float* d_position, float* d_log_scaling, float* d_rotation,
+                   int32_t grad_points_stride, const float* grad_depth, const float* grad_depth_sq,
+                   int32_t grad_depth_stride, float* d_position, float* d_log_scaling, float* d_rotation,
                    float* d_alpha_logit, float* d_T_camera_world, float* d_projection, void* scratch,
                    int64_t scratch_bytes, void* stream);
+
+/* replaces: CameraParams.camera_position (perspective/params.py:76-78, torch.inverse(T)[0:3,3]) for an
+ * affine camera matrix (last row 0 0 0 1), computed on the device without a host round trip. */
+int gs_camera_position(const float* T_camera_world, float* camera_pos, void* stream);
 
 /* ------------------------------------------------------------ spherical harmonics (a4) --
  * replaces: spherical_harmonics.py:118-134 evaluate_sh_at_kernel (+ .grad, :154-161).
  * params (n,C,D) D=(degree+1)^2, degree 0..3, C <= GS_MAX_SH_CHANNELS; positions (n,3);
- * indexes (v) int64 (may repeat); camera_pos 3 floats (device); out (v,C).
+ * indexes (v) int64 (may repeat); camera_pos 3 floats (device); out (v,C), row stride out_stride
+ * (<= 0 means C).  v_dev (optional, device int32): the live row count when v is only a capacity.
  * Backward: d_params (n,C,D) and d_positions (n,3) are zero-filled inside, then written.  When
  * indexes_unique != 0 (the list came from gs_project_fwd) rows are written with plain stores;
  * otherwise with float atomics (the reference test passes repeated indexes,
@@ -108,8 +119,9 @@ int gs_project_bwd(int64_t n, int64_t v, const float* position, const float* log
  * output: when given and neither d_positions nor d_camera_pos is requested, the clamp mask is taken
  * from it (0 < out < 1) and the coefficients are not re-read.
  */
-int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
-              const int64_t* indexes, const float* camera_pos, float* out, void* stream);
+int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
+              const float* positions, const int64_t* indexes, const float* camera_pos, float* out,
+              int32_t out_stride, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,
@@ -127,13 +139,21 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  *     receives the reference's key layout for verification.
  * image size is the UNPADDED (width,height); padding to a tile multiple is internal (:18-22).
  * depth: (v) f32, non-negative (ndc depth).  use_depth16: key layout of :53-59.
- * scratch: gs_map_scratch_bytes(v, num_tiles); pair_scratch: K * 8 bytes.
+ * scratch: gs_map_scratch_bytes(v, num_tiles), the SAME buffer for both calls (prepare leaves the
+ * region ordering in it); pair_scratch: K * 8 bytes.
+ * Asynchronous use (no host read-back between the calls): v may be a capacity with the live count in
+ * v_dev (device int32); k_capacity > 0 bounds the pair / overlap buffers -- tiles that would run
+ * past it are dropped and counts_out[2] is set to 1 so that the caller can retry with more room;
+ * counts_out is int32[4] = {K, fullest tile, overflow flag, 0}; max_tile_count <= 0 in
+ * gs_map_finish means "not read back": its magnitude is only a hint for sizing the per-tile sort
+ * (0 = no hint) and a catch-all launch sorts any fuller tile.
  */
 int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
-int gs_map_prepare(int64_t v, const float* points, int32_t width, int32_t height, const GsRasterConfig* cfg,
-                   int32_t* tile_ranges, int32_t* counts_out, void* scratch, int64_t scratch_bytes, void* stream);
-int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const float* points, const float* depth,
-                  int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
+int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
+                   const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
+                   void* scratch, int64_t scratch_bytes, void* stream);
+int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_count, const float* points,
+                  const float* depth, int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
                   const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys, void* pair_scratch,
                   void* scratch, int64_t scratch_bytes, void* stream);
 

@@ -36,16 +36,18 @@ SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_project_scratch_bytes": (_I64, [_I64]),
     "gs_project_fwd": (ctypes.c_int, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _F64, _F64, _CFG, _P, _P, _P, _P, _P,
-                                       _P, _P, _I64, _P]),
+                                       _P, _P, _I32, _P, _I64, _P]),
     "gs_project_bwd_scratch_bytes": (_I64, [_I64]),
-    "gs_project_bwd": (ctypes.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _P,
-                                       _P, _P, _P, _P, _I64, _P]),
-    "gs_sh_fwd": (ctypes.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P, _P]),
+    "gs_project_bwd": (ctypes.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _CFG, _P, _P, _I32, _P, _P,
+                                       _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "gs_camera_position": (ctypes.c_int, [_P, _P, _P]),
+    "gs_sh_fwd": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
                                   _P]),
     "gs_map_scratch_bytes": (_I64, [_I64, _I64]),
-    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P, _P, _I64, _P]),
-    "gs_map_finish": (ctypes.c_int, [_I64, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _P, _I64, _P]),
+    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _I64, _P]),
+    "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _P, _I64,
+                                      _P]),
     "gs_tile_count": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P]),
     "gs_cumsum_scratch_bytes": (_I64, [_I64]),
     "gs_full_cumsum_i32": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _P]),

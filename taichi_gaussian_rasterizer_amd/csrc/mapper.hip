@@ -96,16 +96,23 @@ __device__ __forceinline__ uint32_t depth_key(float depth, bool depth16) {
 struct MapArgs {
   const float* points;
   const float* depth;
-  int64_t v;
+  int64_t v;            // number of Gaussians, or the buffer capacity when v_dev is set
+  const int* v_dev;     // optional: the actual count lives on the device (no host read-back)
   int Wp, Hp, tile_size, tiles_wide;
   float thr;
   int depth16;
 };
 
+__device__ __forceinline__ int64_t live_count(const MapArgs& a) {
+  if (a.v_dev == nullptr) return a.v;
+  const int64_t d = *a.v_dev;
+  return d < a.v ? d : a.v;
+}
+
 // ---- fused path -------------------------------------------------------------------------
 // single-workgroup exclusive scan over the T-entry histogram (T <= 65536 + slack)
 __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
-                                                        int* cursors, int* counts_out) {
+                                                        int* cursors, int* counts_out, int64_t k_capacity) {
   __shared__ int s_part[1024];
   __shared__ int s_max[1024];
   const int t = threadIdx.x;
@@ -127,11 +134,19 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   int run = s_part[t] - sum;  // exclusive prefix of this thread's chunk
   for (int i = lo; i < hi; ++i) {
     const int c = tile_hist[i];
-    tile_ranges[i] = c > 0 ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
-    cursors[i] = run;
+    // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
+    // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
+    const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
+    tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
+    cursors[i] = fits ? run : -1;
     run += c;
   }
-  if (t == 1023) { counts_out[0] = s_part[1023]; counts_out[1] = s_max[1023]; }
+  if (t == 1023) {
+    counts_out[0] = s_part[1023];
+    counts_out[1] = s_max[1023];
+    counts_out[2] = (k_capacity > 0 && int64_t(s_part[1023]) > k_capacity) ? 1 : 0;
+    counts_out[3] = 0;
+  }
 }
 
 // ---- region-binned counting / bucketing --------------------------------------------------
@@ -168,7 +183,7 @@ __global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid
   for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_hist[r] = 0;
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (i < a.v) {
+  if (i < live_count(a)) {
     const int r = region_of_gaussian(a.points + 7 * i, a, rg);
     region_of[i] = r;
     atomicAdd(&s_hist[r], 1);
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(256) void region_scatter_kernel(MapArgs a, RegionGr
   for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_cnt[r] = 0;
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (i < a.v) {
+  if (i < live_count(a)) {
     const int r = region_of[i];
     const int local = atomicAdd(&s_cnt[r], 1);
     order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = int(i);
@@ -332,7 +347,8 @@ __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid 
     const int c = s_cnt[e];
     if (c > 0) {
       const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
-      s_base[e] = atomicAdd(cursors + gx + gy * a.tiles_wide, c);
+      int* cur = cursors + gx + gy * a.tiles_wide;
+      s_base[e] = *cur < 0 ? -1 : atomicAdd(cur, c);  // -1: tile dropped by the capacity clamp
     }
     s_cnt[e] = 0;
   }
@@ -349,9 +365,12 @@ __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid 
         int slot;
         if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) {
           const int e = ly * WIN + lx;
+          if (s_base[e] < 0) continue;
           slot = s_base[e] + atomicAdd(&s_cnt[e], 1);
         } else {
-          slot = atomicAdd(cursors + gx + gy * a.tiles_wide, 1);
+          int* cur = cursors + gx + gy * a.tiles_wide;
+          if (*cur < 0) continue;
+          slot = atomicAdd(cur, 1);
         }
         pairs[slot] = pair;
       }
@@ -393,27 +412,30 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* data, int n, int t) {
 
 template <int THREADS, int CAP>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const int2* tile_ranges, uint64_t* pairs,
-                                                            int* o2p, uint64_t* keys_out, int depth16) {
+                                                            int* o2p, uint64_t* keys_out, int depth16, int min_n) {
   __shared__ uint64_t s_key[CAP];
-  const int tile = gs_xcd_remap(blockIdx.x, num_tiles);
-  if (tile < 0) return;
-  const int2 r = tile_ranges[tile];
-  const int n = r.y - r.x;
-  if (n <= 0) return;
-  uint64_t* seg = pairs + r.x;
-  const int t = threadIdx.x;
-  uint64_t* data = seg;
-  if (n <= CAP) {
-    for (int i = t; i < n; i += THREADS) s_key[i] = seg[i];
-    data = s_key;
-  }
-  __syncthreads();
-  bitonic_sort<THREADS>(data, n, t);
-  const int shift = depth16 ? 16 : 32;
-  for (int i = t; i < n; i += THREADS) {
-    const uint64_t kv = data[i];
-    o2p[r.x + i] = int(uint32_t(kv));
-    if (keys_out) keys_out[r.x + i] = (kv >> 32) | (uint64_t(uint32_t(tile)) << shift);
+  // grid-stride over the tiles: the kernel is also launched with a small fixed grid as the catch-all
+  // for tiles fuller than the rank sort's limit (min_n > 0), where almost every tile is skipped
+  for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
+    const int2 r = tile_ranges[tile];
+    const int n = r.y - r.x;
+    if (n <= min_n) continue;  // uniform over the workgroup
+    uint64_t* seg = pairs + r.x;
+    const int t = threadIdx.x;
+    uint64_t* data = seg;
+    if (n <= CAP) {
+      for (int i = t; i < n; i += THREADS) s_key[i] = seg[i];
+      data = s_key;
+    }
+    __syncthreads();
+    bitonic_sort<THREADS>(data, n, t);
+    const int shift = depth16 ? 16 : 32;
+    for (int i = t; i < n; i += THREADS) {
+      const uint64_t kv = data[i];
+      o2p[r.x + i] = int(uint32_t(kv));
+      if (keys_out) keys_out[r.x + i] = (kv >> 32) | (uint64_t(uint32_t(tile)) << shift);
+    }
+    __syncthreads();
   }
 }
 
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const
   if (tile < 0) return;
   const int2 r = tile_ranges[tile];
   const int n = r.y - r.x;
-  if (n <= 0) return;
+  if (n <= 0 || n > 64 * RMAX) return;  // fuller tiles belong to the bitonic kernel
   const uint64_t* seg = pairs + r.x;
   const int lane = threadIdx.x;
   for (int i = lane; i < n; i += 64) s_key[i] = seg[i];
@@ -476,7 +498,7 @@ __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const
 // ---- reference-shaped primitives ----------------------------------------------------------
 __global__ __launch_bounds__(256) void tile_count_kernel(MapArgs a, int* counts) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.v) return;
+  if (i >= live_count(a)) return;
   const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
   int c = 0;
   for (int ty = 0; ty < q.span_y; ++ty)
@@ -487,7 +509,7 @@ __global__ __launch_bounds__(256) void tile_count_kernel(MapArgs a, int* counts)
 __global__ __launch_bounds__(256) void tile_emit_keys_kernel(MapArgs a, const int* offsets, uint64_t* keys,
                                                              int* values) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= a.v) return;
+  if (i >= live_count(a)) return;
   const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
   int64_t k = offsets[i];
   const uint64_t dk = depth_key(a.depth[i], a.depth16 != 0);
@@ -589,7 +611,7 @@ int fill_args(MapArgs& a, int64_t v, const float* points, const float* depth, in
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "mapper: image size %dx%d", width, height);
   GS_REQUIRE(v >= 0 && v < (int64_t(1) << 31), GS_ERR_INVALID_ARGUMENT, "mapper: %lld gaussians", (long long)v);
   const int ts = cfg->tile_size;
-  a.points = points; a.depth = depth; a.v = v;
+  a.points = points; a.depth = depth; a.v = v; a.v_dev = nullptr;
   a.Wp = int(gs_div_up(width, ts)) * ts;  // pad_to_tile, tile_mapper.py:18-22
   a.Hp = int(gs_div_up(height, ts)) * ts;
   a.tile_size = ts;
@@ -641,11 +663,12 @@ extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
          gs_align_up((MAX_REGIONS + 1) * 4, 256) * 3 + gs_align_up(part_entries(v, num_tiles) * 4, 256);
 }
 
-extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int32_t height,
-                              const GsRasterConfig* cfg, int32_t* tile_ranges, int32_t* counts_out, void* scratch,
-                              int64_t scratch_bytes, void* stream) {
+extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
+                              const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges,
+                              int32_t* counts_out, void* scratch, int64_t scratch_bytes, void* stream) {
   MapArgs a;
   if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0)) return rc;
+  a.v_dev = v_dev;
   const int num_tiles = a.tiles_wide * (a.Hp / a.tile_size);
   GS_REQUIRE(tile_ranges && counts_out && scratch, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: NULL buffer");
   GS_REQUIRE(scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
@@ -679,17 +702,19 @@ extern "C" int gs_map_prepare(int64_t v, const float* points, int32_t width, int
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
   hipLaunchKernelGGL(map_scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist,
-                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out);
+                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity);
   GS_CHECK_LAUNCH("gs_map_prepare/scan");
   return GS_OK;
 }
 
-extern "C" int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const float* points, const float* depth,
-                             int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
-                             const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys,
-                             void* pair_scratch, void* scratch, int64_t scratch_bytes, void* stream) {
+extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_count, const float* points,
+                             const float* depth, int32_t width, int32_t height, const GsRasterConfig* cfg,
+                             int32_t use_depth16, const int32_t* tile_ranges, int32_t* overlap_to_point,
+                             uint64_t* sorted_keys, void* pair_scratch, void* scratch, int64_t scratch_bytes,
+                             void* stream) {
   MapArgs a;
   if (int rc = fill_args(a, v, points, depth, width, height, cfg, use_depth16)) return rc;
+  a.v_dev = v_dev;
   if (k == 0 || v == 0) return GS_OK;
   const int num_tiles = a.tiles_wide * (a.Hp / a.tile_size);
   GS_REQUIRE(points && depth && tile_ranges && overlap_to_point && pair_scratch && scratch, GS_ERR_INVALID_ARGUMENT,
@@ -707,21 +732,31 @@ extern "C" int gs_map_finish(int64_t v, int64_t k, int32_t max_tile_count, const
   GS_CHECK_LAUNCH("gs_map_finish/emit");
   const int grid = 8 * int(gs_div_up(num_tiles, 8));
   const int2* r = reinterpret_cast<const int2*>(tile_ranges);
-  if (max_tile_count <= 256)
+  // max_tile_count > 0: exact population of the fullest tile (read back by the caller);
+  // max_tile_count <= 0: unknown -- |max_tile_count| is a hint (0 = none).  The rank sort is sized from
+  // it and a small persistent bitonic launch catches any fuller tile, so a wrong hint costs time only.
+  const bool exact = max_tile_count > 0;
+  const int guess = exact ? max_tile_count : (max_tile_count < 0 ? -max_tile_count : 1024);
+  int covered;
+  if (guess <= 256) {
+    covered = 256;
     hipLaunchKernelGGL((tile_rank_sort_kernel<4>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
                        sorted_keys, use_depth16);
-  else if (max_tile_count <= 512)
+  } else if (guess <= 512) {
+    covered = 512;
     hipLaunchKernelGGL((tile_rank_sort_kernel<8>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
                        sorted_keys, use_depth16);
-  else if (max_tile_count <= 1024)
+  } else {
+    covered = 1024;
     hipLaunchKernelGGL((tile_rank_sort_kernel<16>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs,
                        overlap_to_point, sorted_keys, use_depth16);
-  else if (max_tile_count <= 2048)
-    hipLaunchKernelGGL((tile_sort_kernel<256, 2048>), dim3(grid), dim3(256), 0, s, num_tiles, r, pairs,
-                       overlap_to_point, sorted_keys, use_depth16);
-  else
-    hipLaunchKernelGGL((tile_sort_kernel<1024, 8192>), dim3(grid), dim3(1024), 0, s, num_tiles, r, pairs,
-                       overlap_to_point, sorted_keys, use_depth16);
+  }
+  if (!exact)
+    hipLaunchKernelGGL((tile_sort_kernel<1024, 8192>), dim3(min(num_tiles, 256)), dim3(1024), 0, s, num_tiles, r, pairs,
+                       overlap_to_point, sorted_keys, use_depth16, covered);
+  else if (max_tile_count > covered)
+    hipLaunchKernelGGL((tile_sort_kernel<1024, 8192>), dim3(min(num_tiles, 2048)), dim3(1024), 0, s, num_tiles, r,
+                       pairs, overlap_to_point, sorted_keys, use_depth16, covered);
   GS_CHECK_LAUNCH("gs_map_finish/sort");
   return GS_OK;
 }

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_row
 __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* st_rows, const int* block_offsets,
                                                       int num_blocks, float inv_far, float ndc_denom, float* points,
                                                       float* depth, float* ndc, int64_t* indexes, int* slot_of,
-                                                      int* num_visible) {
+                                                      int* num_visible, float* depth_feat, int depth_feat_stride) {
   __shared__ int s_cnt[4];
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
@@ -162,6 +162,10 @@ __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* s
       float* p = points + int64_t(slot) * 7;
       p[0] = r0.x; p[1] = r0.y; p[2] = r0.z; p[3] = r0.w; p[4] = r1.x; p[5] = r1.y; p[6] = r1.z;
       depth[slot] = r1.w;
+      if (depth_feat) {  // renderer.py:191-193: raster features [z, z^2, ...]
+        depth_feat[int64_t(slot) * depth_feat_stride] = r1.w;
+        depth_feat[int64_t(slot) * depth_feat_stride + 1] = r1.w * r1.w;
+      }
       // fixed f32 op order: the sort key is the bit pattern of this value
       const float inv_d = __fdiv_rn(1.0f, r1.w);
       ndc[slot] = 1.0f - __fdiv_rn(inv_d - inv_far, ndc_denom);
@@ -176,8 +180,10 @@ __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* s
 struct BwdArgs {
   ProjArgs f;
   const int* slot_of;
-  const float* gpoints;  // (V,7) or null
-  const float* gdepth;   // (V) or null
+  const float* gpoints;  // row stride gpoints_stride, or null
+  const float* gdepth;   // stride gdepth_stride, or null
+  const float* gdepth_sq;  // optional gradient of a z^2 feature (adds 2 z g), same stride as gdepth
+  int gpoints_stride, gdepth_stride;
   float* d_position;
   float* d_log_scaling;
   float* d_rotation;
@@ -201,9 +207,10 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdArgs a) {
       float g[7] = {0, 0, 0, 0, 0, 0, 0}, gz = 0.0f;
       if (a.gpoints) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) g[k] = a.gpoints[int64_t(slot) * 7 + k];
+        for (int k = 0; k < 7; ++k) g[k] = a.gpoints[int64_t(slot) * a.gpoints_stride + k];
       }
-      if (a.gdepth) gz = a.gdepth[slot];
+      if (a.gdepth) gz = a.gdepth[int64_t(slot) * a.gdepth_stride];
+      if (a.gdepth_sq) gz += 2.0f * f.cam[2] * a.gdepth_sq[int64_t(slot) * a.gdepth_stride];
       // alpha = sigmoid(logit)
       dal = g[6] * f.alpha * (1.0f - f.alpha);
       // sigma = sqrt(lambda)
@@ -342,6 +349,24 @@ __global__ __launch_bounds__(256) void cam_reduce_kernel(int num_blocks, const f
   if (threadIdx.x < 4 && dT44) dT44[12 + threadIdx.x] = 0.0f;
 }
 
+// camera position = -R^-1 t of the (affine) camera matrix, on the device: CameraParams.camera_position
+// (params.py:76-78) without the host round trip of a 4x4 torch.inverse
+__global__ void camera_position_kernel(const float* T, float* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
+  const float tx = T[3], ty = T[7], tz = T[11];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  const float inv = 1.0f / det;
+  // inverse(R) rows
+  const float r00 = A * inv, r01 = -(b * i - c * h) * inv, r02 = (b * f - c * e) * inv;
+  const float r10 = B * inv, r11 = (a * i - c * g) * inv, r12 = -(a * f - c * d) * inv;
+  const float r20 = C * inv, r21 = -(a * h - b * g) * inv, r22 = (a * e - b * d) * inv;
+  out[0] = -(r00 * tx + r01 * ty + r02 * tz);
+  out[1] = -(r10 * tx + r11 * ty + r12 * tz);
+  out[2] = -(r20 * tx + r21 * ty + r22 * tz);
+}
+
 int fill(ProjArgs& a, int64_t n, const float* position, const float* log_scaling, const float* rotation,
          const float* alpha_logit, const float* T, const float* proj, int width, int height, double near_p,
          double far_p, const GsRasterConfig* cfg) {
@@ -372,8 +397,8 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
                               const float* alpha_logit, const float* T_camera_world, const float* projection,
                               int32_t width, int32_t height, double near_plane, double far_plane,
                               const GsRasterConfig* cfg, float* points, float* depth, float* ndc_depth,
-                              int64_t* indexes, int32_t* slot_of, int32_t* num_visible, void* scratch,
-                              int64_t scratch_bytes, void* stream) {
+                              int64_t* indexes, int32_t* slot_of, int32_t* num_visible, float* depth_features,
+                              int32_t depth_features_stride, void* scratch, int64_t scratch_bytes, void* stream) {
   ProjArgs a;
   if (int rc = fill(a, n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
                     near_plane, far_plane, cfg))
@@ -399,7 +424,7 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
   GS_CHECK_LAUNCH("gs_project_fwd/project");
   if (int rc = gs_full_cumsum_i32(nb, counts, offsets, scan_scratch, gs_cumsum_scratch_bytes(nb), s)) return rc;
   hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, s, n, st_rows, offsets, nb, a.inv_far, a.ndc_denom,
-                     points, depth, ndc_depth, indexes, slot_of, num_visible);
+                     points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride);
   GS_CHECK_LAUNCH("gs_project_fwd/compact");
   return GS_OK;
 }
@@ -409,7 +434,8 @@ extern "C" int64_t gs_project_bwd_scratch_bytes(int64_t n) { return gs_align_up(
 extern "C" int gs_project_bwd(int64_t n, int64_t v, const float* position, const float* log_scaling,
                               const float* rotation, const float* alpha_logit, const float* T_camera_world,
                               const float* projection, int32_t width, int32_t height, const GsRasterConfig* cfg,
-                              const int32_t* slot_of, const float* grad_points, const float* grad_depth,
+                              const int32_t* slot_of, const float* grad_points, int32_t grad_points_stride,
+                              const float* grad_depth, const float* grad_depth_sq, int32_t grad_depth_stride,
                               float* d_position, float* d_log_scaling, float* d_rotation, float* d_alpha_logit,
                               float* d_T_camera_world, float* d_projection, void* scratch, int64_t scratch_bytes,
                               void* stream) {
@@ -425,7 +451,9 @@ extern "C" int gs_project_bwd(int64_t n, int64_t v, const float* position, const
   const int nb = int(gs_div_up(n, 256));
   GS_REQUIRE(!camera || (scratch && scratch_bytes >= int64_t(nb) * 64), GS_ERR_SCRATCH_TOO_SMALL,
              "gs_project_bwd: camera gradients need %lld bytes of scratch", (long long)(int64_t(nb) * 64));
-  b.slot_of = slot_of; b.gpoints = grad_points; b.gdepth = grad_depth;
+  b.slot_of = slot_of; b.gpoints = grad_points; b.gdepth = grad_depth; b.gdepth_sq = grad_depth_sq;
+  b.gpoints_stride = grad_points_stride > 0 ? grad_points_stride : 7;
+  b.gdepth_stride = grad_depth_stride > 0 ? grad_depth_stride : 1;
   b.d_position = d_position; b.d_log_scaling = d_log_scaling; b.d_rotation = d_rotation;
   b.d_alpha_logit = d_alpha_logit;
   b.cam_partials = static_cast<float*>(scratch);
@@ -438,5 +466,13 @@ extern "C" int gs_project_bwd(int64_t n, int64_t v, const float* position, const
     hipLaunchKernelGGL(project_bwd_kernel<false>, dim3(nb), dim3(256), 0, s, b);
   }
   GS_CHECK_LAUNCH("gs_project_bwd");
+  return GS_OK;
+}
+
+extern "C" int gs_camera_position(const float* T_camera_world, float* camera_pos, void* stream) {
+  GS_REQUIRE(T_camera_world && camera_pos, GS_ERR_INVALID_ARGUMENT, "gs_camera_position: NULL buffer");
+  hipLaunchKernelGGL(camera_position_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), T_camera_world,
+                     camera_pos);
+  GS_CHECK_LAUNCH("gs_camera_position");
   return GS_OK;
 }

@@ -75,10 +75,12 @@ __device__ __forceinline__ void load_row(const float* row, float* out) {
 }
 
 template <int DEG>
-__global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, int C, const float* params, const float* positions,
-                                                     const int64_t* indexes, const float* cam, float* out) {
+__global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev, int C, const float* params,
+                                                     const float* positions, const int64_t* indexes,
+                                                     const float* cam, float* out, int out_stride) {
   constexpr int D = (DEG + 1) * (DEG + 1);
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (v_dev != nullptr && i >= *v_dev) return;
   if (i >= v) return;
   const int64_t idx = indexes[i];
   const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1], dz = positions[3 * idx + 2] - cam[2];
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, int C, const flo
     float acc = 0.0f;
 #pragma unroll
     for (int d = 0; d < D; ++d) acc += Y[d] * row[d];
-    out[i * C + c] = fminf(fmaxf(acc + 0.5f, 0.0f), 1.0f);
+    out[i * out_stride + c] = fminf(fmaxf(acc + 0.5f, 0.0f), 1.0f);
   }
 }
 
@@ -248,19 +250,24 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
 
 }  // namespace
 
-extern "C" int gs_sh_fwd(int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
-                         const int64_t* indexes, const float* camera_pos, float* out, void* stream) {
+extern "C" int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
+                         const float* positions, const int64_t* indexes, const float* camera_pos, float* out,
+                         int32_t out_stride, void* stream) {
   GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "gs_sh_fwd: SH degree %d not in [0,3]", degree);
   GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "gs_sh_fwd: %d channels", channels);
   if (v == 0) return GS_OK;
   GS_REQUIRE(params && positions && indexes && camera_pos && out, GS_ERR_INVALID_ARGUMENT, "gs_sh_fwd: NULL buffer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (out_stride <= 0) out_stride = channels;
   const dim3 grid(unsigned(gs_div_up(v, 256))), block(256);
+#define SH_FWD(DEG)                                                                                               \
+  hipLaunchKernelGGL(sh_fwd_kernel<DEG>, grid, block, 0, s, v, v_dev, channels, params, positions, indexes,       \
+                     camera_pos, out, out_stride)
   switch (degree) {
-    case 0: hipLaunchKernelGGL(sh_fwd_kernel<0>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
-    case 1: hipLaunchKernelGGL(sh_fwd_kernel<1>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
-    case 2: hipLaunchKernelGGL(sh_fwd_kernel<2>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
-    default: hipLaunchKernelGGL(sh_fwd_kernel<3>, grid, block, 0, s, v, channels, params, positions, indexes, camera_pos, out); break;
+    case 0: SH_FWD(0); break;
+    case 1: SH_FWD(1); break;
+    case 2: SH_FWD(2); break;
+    default: SH_FWD(3); break;
   }
   GS_CHECK_LAUNCH("gs_sh_fwd");
   return GS_OK;

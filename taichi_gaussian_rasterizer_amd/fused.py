@@ -1,0 +1,227 @@
+"""Fused frame: the whole render_gaussians pipeline as ONE autograd node.
+
+Same kernels as the operator-by-operator composition in renderer.py, but enqueued back to back
+on the stream with the intermediate counts (visible Gaussians V, overlaps K) left on the device:
+
+  * no host read-back between the stages -- the single synchronisation is at the END of the forward,
+    when the tensor shapes of the result (V rows) have to be known to Python;
+  * no torch glue on the path: the SH colours and the depth features are written straight into the
+    rasterizer's feature rows, the rasterizer's 64-byte gradient rows are consumed in place by the SH
+    and projection backward (no unpack, no cat/index backward, no zero-filled dense temporaries);
+  * the pair / overlap buffers are sized from the previous frame's K (x1.3); the mapper clamps to the
+    capacity and raises a flag, in which case the frame is re-run once with exact sizes.
+
+This is SURVEY.md 8(f)-1: in the reference that glue is ~24 % of the forward+backward GPU time
+(profiles/bicycle_2048.txt:38,42,44,47).  Results are bit-identical to the composed operators.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _native as nv
+from .data_types import RasterConfig
+from .spherical_harmonics import check_sh_degree
+
+_K_HINT = {}  # (n, w, h, tile_size, use_depth16) -> (max overlaps, max tile population) seen for that shape
+_PINNED = {}  # device index -> ring of pinned int32[8] host buffers for the asynchronous count read-back
+
+
+def _pinned_counts(dev: torch.device) -> torch.Tensor:
+    ring = _PINNED.setdefault(dev.index, dict(bufs=[torch.empty((8,), dtype=torch.int32).pin_memory()
+                                                    for _ in range(4)], at=0))
+    ring["at"] = (ring["at"] + 1) % len(ring["bufs"])
+    return ring["bufs"][ring["at"]]
+
+
+def _off(t: torch.Tensor, floats: int) -> ctypes.c_void_p:
+    return ctypes.c_void_p(t.data_ptr() + 4 * floats)
+
+
+class _FusedRender(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
+                image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool):
+        nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
+                          what="render_gaussians")
+        lib = nv.lib()
+        dev = position.device
+        n = position.shape[0]
+        w, h = int(image_size[0]), int(image_size[1])
+        C = feature.shape[1]
+        degree = check_sh_degree(feature)
+        F = C + (2 if render_depth else 0)
+        col0 = F - C
+        cfg = nv.make_config(config)
+        ts = config.tile_size
+        tile_shape = (-(-h // ts), -(-w // ts))
+        num_tiles = tile_shape[0] * tile_shape[1]
+        T = T_camera_world.contiguous()
+        proj = projection.contiguous()
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        points = torch.empty((n, 7), **f32)
+        depth = torch.empty((n, 1), **f32)
+        ndc = torch.empty((n, 1), **f32)
+        feats = torch.empty((n, F), **f32)
+        indexes = torch.empty((n,), dtype=torch.int64, device=dev)
+        slot_of = torch.empty((n,), dtype=torch.int32, device=dev)
+        counts = torch.zeros((8,), dtype=torch.int32, device=dev)  # [0] = V ; [4:8] = K, fullest tile, overflow, -
+        cam_pos = torch.empty((3,), **f32)
+        pbytes = lib.gs_project_scratch_bytes(n)
+        pscratch = torch.empty((max(pbytes, 1),), dtype=torch.uint8, device=dev)
+        s = nv.stream()
+        nv.check(lib.gs_project_fwd(n, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
+                                    nv.ptr(T), nv.ptr(proj), w, h, float(depth_range[0]), float(depth_range[1]), cfg,
+                                    nv.ptr(points), nv.ptr(depth), nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of),
+                                    nv.ptr(counts), nv.ptr(feats) if render_depth else None, F, nv.ptr(pscratch),
+                                    pbytes, s), "gs_project_fwd")
+        nv.check(lib.gs_camera_position(nv.ptr(T), nv.ptr(cam_pos), s), "gs_camera_position")
+        v_dev = nv.ptr(counts)
+        nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
+                               nv.ptr(cam_pos), _off(feats, col0), F, s), "gs_sh_fwd")
+
+        tile_ranges = torch.empty((*tile_shape, 2), dtype=torch.int32, device=dev)
+        mbytes = lib.gs_map_scratch_bytes(n, num_tiles)
+        mscratch = torch.empty((mbytes,), dtype=torch.uint8, device=dev)
+        want_vis = config.compute_visibility or config.compute_point_heuristic
+        key = (n, w, h, ts, bool(use_depth16))
+        hint = _K_HINT.get(key)
+        k_cap = 0 if hint is None else int(hint[0] * 1.25) + 4096
+        tile_hint = 0 if hint is None else -max(int(hint[1]), 1)  # sizing hint only; fuller tiles are still sorted
+        host_counts = _pinned_counts(dev)
+        ready = torch.cuda.Event()
+
+        def map_and_raster(k_cap):
+            nv.check(lib.gs_map_prepare(n, v_dev, nv.ptr(points), w, h, cfg, k_cap, nv.ptr(tile_ranges),
+                                        _off(counts, 4), nv.ptr(mscratch), mbytes, s), "gs_map_prepare")
+            # V, K and the overflow flag are final here: copy them out asynchronously and keep enqueueing;
+            # the host waits on this event while the sort and the rasterizer are still running
+            host_counts.copy_(counts, non_blocking=True)
+            ready.record()
+            if k_cap == 0:  # first frame of this shape: K has to be known to size the buffers
+                ready.synchronize()
+                k_cap = max(int(host_counts[4]), 1)
+            o2p = torch.empty((k_cap,), dtype=torch.int32, device=dev)
+            pairs = torch.empty((k_cap,), dtype=torch.int64, device=dev)
+            nv.check(lib.gs_map_finish(n, v_dev, k_cap, tile_hint, nv.ptr(points), nv.ptr(ndc), w, h, cfg,
+                                       int(use_depth16),
+                                       nv.ptr(tile_ranges), nv.ptr(o2p), None, nv.ptr(pairs), nv.ptr(mscratch),
+                                       mbytes, s), "gs_map_finish")
+            image = torch.empty((h, w, F), **f32)
+            alpha = torch.empty((h, w), **f32)
+            vis = torch.zeros((n,), **f32) if want_vis else None
+            nv.check(lib.gs_raster_fwd(n, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), k_cap,
+                                       w, h, cfg, nv.ptr(image), nv.ptr(alpha), nv.ptr(vis), s), "gs_raster_fwd")
+            return o2p, image, alpha, vis
+
+        o2p, image, alpha, vis = map_and_raster(k_cap)
+        ready.synchronize()  # waits for the mapper's scan only, not for the rasterizer
+        host = host_counts.tolist()
+        V, K, max_tile, overflow = host[0], host[4], host[5], host[6]
+        if overflow:  # more overlaps than the hint allowed for: run the tail again with exact sizes
+            o2p, image, alpha, vis = map_and_raster(max(K, 1))
+            ready.synchronize()
+        _K_HINT[key] = (max(K, hint[0]) if hint else K, max(max_tile, hint[1]) if hint else max_tile)
+
+        points_v, depth_v, indexes_v = points[:V], depth[:V], indexes[:V]
+        empty = torch.empty((0,), **f32)
+        vis_out = vis[:V] if config.compute_visibility else empty
+        heur = torch.zeros((V, 2), **f32) if config.compute_point_heuristic else torch.empty((0, 2), **f32)
+
+        ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, F=F, C=C, col0=col0, degree=degree, config=config,
+                        render_depth=render_depth)
+        ctx.heur = heur
+        ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
+                              indexes, cam_pos, tile_ranges, o2p, image)
+        ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur)
+        return image, alpha, points_v, depth_v, indexes_v, vis_out, heur
+
+    @staticmethod
+    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur):
+        (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
+         tile_ranges, o2p, image) = ctx.saved_tensors
+        m = ctx.meta
+        lib = nv.lib()
+        dev = position.device
+        n, V, K, w, h, F, C, col0 = m["n"], m["V"], m["K"], m["w"], m["h"], m["F"], m["C"], m["col0"]
+        config = m["config"]
+        cfg = nv.make_config(config)
+        s = nv.stream()
+        RS = lib.gs_grad_row_floats(F)
+        rows = torch.zeros((max(V, 1), RS), dtype=torch.float32, device=dev)
+        if g_image is not None and V > 0:
+            gi = g_image.contiguous()
+            nv.require_device(gi, what="render_gaussians backward")
+            nv.check(lib.gs_raster_bwd(V, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), K, w, h,
+                                       cfg, nv.ptr(image), nv.ptr(gi), nv.ptr(rows), s), "gs_raster_bwd")
+        if config.compute_point_heuristic and V > 0:
+            ctx.heur.copy_(rows[:V, 7 + F:9 + F])
+        # gradients a caller attached to the projected splats / depths themselves (e.g. a regulariser)
+        if g_points is not None and V > 0:
+            rows[:V, :7] += g_points
+        extra_depth = None
+        if g_depth is not None and V > 0:
+            if m["render_depth"]:
+                rows[:V, 7] += g_depth.reshape(-1)
+            else:
+                extra_depth = g_depth.contiguous()
+
+        d_feature = torch.empty_like(feature)
+        nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
+                               nv.ptr(slot_of), nv.ptr(cam_pos), _off(rows, 7 + col0), RS, _off(feats, col0), F,
+                               nv.ptr(d_feature), None, None, s), "gs_sh_bwd")
+
+        need_T, need_proj = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
+        d_pos, d_ls = torch.empty_like(position), torch.empty_like(log_scaling)
+        d_rot, d_al = torch.empty_like(rotation), torch.empty_like(alpha_logit)
+        d_T = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_T else None
+        d_proj = torch.empty((4,), dtype=torch.float32, device=dev) if need_proj else None
+        nbytes = lib.gs_project_bwd_scratch_bytes(n) if (need_T or need_proj) else 0
+        scratch = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
+        if m["render_depth"]:
+            gd, gd2, gstride = _off(rows, 7), _off(rows, 8), RS
+        else:
+            gd, gd2, gstride = nv.ptr(extra_depth), None, 1
+        nv.check(lib.gs_project_bwd(n, V, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
+                                    nv.ptr(T), nv.ptr(proj), w, h, cfg, nv.ptr(slot_of), nv.ptr(rows), RS, gd, gd2,
+                                    gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot), nv.ptr(d_al), nv.ptr(d_T),
+                                    nv.ptr(d_proj), nv.ptr(scratch), nbytes, s), "gs_project_bwd")
+        return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None
+
+
+def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
+    """The fused node covers the SH-colour frame (the training path).  Anything else -- plain
+    feature gather, median depth, a camera matrix that itself requires grad (its gradient reaches the
+    SH view direction through torch.inverse in the reference) -- runs the composed operators."""
+    if not use_sh or render_median_depth:
+        return False
+    f = gaussians.feature
+    if gaussians.position.shape[0] == 0:
+        return False
+    if f.ndim != 3 or f.shape[1] > 8 or not f.is_cuda or f.dtype != torch.float32:
+        return False
+    if camera_params.T_camera_world.requires_grad:
+        return False
+    return True
+
+
+def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool):
+    from .renderer import Rendering, compute_depth_variance
+    image, alpha, g2d, depths, indexes, vis, heur = _FusedRender.apply(
+        gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
+        gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
+        camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
+        use_depth16)
+    indexes._gs_unique = True
+    img_depth = img_var = None
+    feature_image = image
+    if render_depth:
+        img_depth, img_var = compute_depth_variance(image[..., :2], alpha)
+        feature_image = image[..., 2:]
+    return Rendering(image=feature_image, image_weight=alpha, depth=img_depth, depth_var=img_var,
+                     camera=camera_params, config=config,
+                     point_visibility=vis if config.compute_visibility else None,
+                     point_heuristic=heur if config.compute_point_heuristic else None,
+                     points_in_view=indexes, point_depth=depths, gaussians2d=g2d)

@@ -64,17 +64,17 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
     w, h = int(image_size[0]), int(image_size[1])
 
     tile_ranges = torch.empty((*tile_shape, 2), dtype=torch.int32, device=dev)
-    counts = torch.empty((2,), dtype=torch.int32, device=dev)
+    counts = torch.empty((4,), dtype=torch.int32, device=dev)
     nbytes = lib.gs_map_scratch_bytes(v, num_tiles)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-    nv.check(lib.gs_map_prepare(v, nv.ptr(g), w, h, cfg, nv.ptr(tile_ranges), nv.ptr(counts), nv.ptr(scratch),
-                                nbytes, nv.stream()), "gs_map_prepare")
-    k, max_tile = (int(x) for x in counts.tolist())  # host sync (reference: full_cumsum.cu:45)
+    nv.check(lib.gs_map_prepare(v, None, nv.ptr(g), w, h, cfg, 0, nv.ptr(tile_ranges), nv.ptr(counts),
+                                nv.ptr(scratch), nbytes, nv.stream()), "gs_map_prepare")
+    k, max_tile = (int(x) for x in counts[:2].tolist())  # host sync (reference: full_cumsum.cu:45)
     overlap_to_point = torch.empty((k,), dtype=torch.int32, device=dev)
     keys = torch.empty((k,), dtype=torch.int64, device=dev) if return_keys else None
     if k > 0:
         pairs = torch.empty((k,), dtype=torch.int64, device=dev)
-        nv.check(lib.gs_map_finish(v, k, max_tile, nv.ptr(g), nv.ptr(d), w, h, cfg, int(use_depth16),
+        nv.check(lib.gs_map_finish(v, None, k, max_tile, nv.ptr(g), nv.ptr(d), w, h, cfg, int(use_depth16),
                                    nv.ptr(tile_ranges), nv.ptr(overlap_to_point), nv.ptr(keys), nv.ptr(pairs),
                                    nv.ptr(scratch), nbytes, nv.stream()), "gs_map_finish")
     if return_keys:

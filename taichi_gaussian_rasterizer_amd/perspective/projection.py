@@ -47,8 +47,8 @@ class _ProjectFunction(torch.autograd.Function):
         nv.check(lib.gs_project_fwd(n, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
                                     nv.ptr(T), nv.ptr(proj), int(image_size[0]), int(image_size[1]),
                                     float(depth_range[0]), float(depth_range[1]), cfg, nv.ptr(points), nv.ptr(depth),
-                                    nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of), nv.ptr(count), nv.ptr(scratch),
-                                    nbytes, nv.stream()), "gs_project_fwd")
+                                    nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of), nv.ptr(count), None, 0,
+                                    nv.ptr(scratch), nbytes, nv.stream()), "gs_project_fwd")
         v = int(count.item())  # the one host sync of the stage (the reference's torch.nonzero, :146)
         points, depth, ndc, indexes = points[:v], depth[:v], ndc[:v], indexes[:v]
         ctx.image_size = (int(image_size[0]), int(image_size[1]))
@@ -79,8 +79,8 @@ class _ProjectFunction(torch.autograd.Function):
         nv.require_device(gp, gd, what="project_to_image backward")
         nv.check(lib.gs_project_bwd(n, ctx.num_visible, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation),
                                     nv.ptr(alpha_logit), nv.ptr(T), nv.ptr(proj), ctx.image_size[0],
-                                    ctx.image_size[1], nv.make_config(ctx.config), nv.ptr(slot_of), nv.ptr(gp),
-                                    nv.ptr(gd), nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot), nv.ptr(d_al),
+                                    ctx.image_size[1], nv.make_config(ctx.config), nv.ptr(slot_of), nv.ptr(gp), 7,
+                                    nv.ptr(gd), None, 1, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot), nv.ptr(d_al),
                                     nv.ptr(d_T), nv.ptr(d_proj), nv.ptr(scratch), nbytes, nv.stream()),
                  "gs_project_bwd")
         return d_pos, d_ls, d_rot, d_al, d_T, d_proj, None, None, None

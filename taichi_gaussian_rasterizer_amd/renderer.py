@@ -137,6 +137,11 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
         if not isinstance(flag, bool):
             raise TypeError(f"{name} must be bool")
 
+    from .fused import fused_supported, render_fused
+    if fused_supported(gaussians, camera_params, use_sh, render_median_depth):
+        # one autograd node, no host read-backs between stages, no torch glue (fused.py)
+        return render_fused(gaussians, camera_params, config, render_depth, use_depth16)
+
     gaussians2d, depths, indexes, ndc_depths = project_with_ndc(
         *gaussians.shape_tensors(), camera_params.T_camera_world, camera_params.projection,
         camera_params.image_size, camera_params.depth_range, config)

@@ -30,8 +30,8 @@ class _SHFunction(torch.autograd.Function):
         lib = nv.lib()
         v, C = indexes.shape[0], params.shape[1]
         out = torch.empty((v, C), dtype=torch.float32, device=params.device)
-        nv.check(lib.gs_sh_fwd(v, C, degree, nv.ptr(params), nv.ptr(points), nv.ptr(indexes), nv.ptr(camera_pos),
-                               nv.ptr(out), nv.stream()), "gs_sh_fwd")
+        nv.check(lib.gs_sh_fwd(v, None, C, degree, nv.ptr(params), nv.ptr(points), nv.ptr(indexes),
+                               nv.ptr(camera_pos), nv.ptr(out), C, nv.stream()), "gs_sh_fwd")
         ctx.save_for_backward(params, points, indexes, camera_pos, out)
         ctx.degree, ctx.unique, ctx.slot_of = degree, unique, slot_of
         return out

@@ -489,3 +489,54 @@ def test_full_size_c3_properties():
     out = gs.rasterize_with_tiles(p_t, feats, o2p, ranges.view(-1, 2), size, cfg)
     (out.image.sum() * 2.0).backward()
     pu.assert_grad_close(p_t.grad, 2.0 * g1, "backward linearity", tol=1e-4)
+
+
+# ------------------------------------------------------------------------------ fused frame
+@pytest.mark.parametrize("depth_mode,heur", [(False, False), (True, False), (False, True)])
+def test_fused_frame_equals_composed_operators(depth_mode, heur):
+    """fused.py (one autograd node, device-side counts) against the operator-by-operator composition:
+    identical forward, gradients equal up to the order of the float atomics; repeated frames exercise
+    the capacity hint and the overflow re-run."""
+    from taichi_gaussian_rasterizer_amd import fused
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    size = (256, 192)
+    cfg = RasterConfig(compute_visibility=heur, compute_point_heuristic=heur)
+    gi = dev(torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(3)))
+    fused._K_HINT.clear()
+    for it, n in enumerate((8000, 8000, 30000, 500)):  # 3rd frame overflows the hint of the 2nd (same key? no: n differs)
+        g, camera = scenes.benchmark_scene(n, size, sh_degree=3, seed=it)
+        cam = camera.to(device=DEV)
+        a = g.to(DEV).requires_grad_(True)
+        r = gs.render_gaussians(a, cam, cfg, use_sh=True, render_depth=depth_mode)
+        b = g.to(DEV).requires_grad_(True)
+        g2d, depths, idx, ndc = hip_proj.project_with_ndc(*b.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                          cam.image_size, cam.depth_range, cfg)
+        feats = gs.evaluate_sh_at(b.feature, b.position.detach(), idx, cam.camera_position)
+        r2 = render_projected(idx, g2d, feats, depths, cam, cfg, render_depth=depth_mode, ndc_depths=ndc)
+        assert torch.equal(r.points_in_view, r2.points_in_view) and torch.equal(r.gaussians2d, r2.gaussians2d)
+        assert torch.equal(r.image, r2.image) and torch.equal(r.image_weight, r2.image_weight)
+        la, lb = (r.image * gi).sum(), (r2.image * gi).sum()
+        if depth_mode:
+            assert torch.equal(r.depth, r2.depth)
+            la, lb = la + r.depth.sum() + 0.1 * r.depth_var.sum(), lb + r2.depth.sum() + 0.1 * r2.depth_var.sum()
+        la.backward()
+        lb.backward()
+        for k, t in a.items():
+            pu.assert_grad_close(t.grad, getattr(b, k).grad, f"fused grad {k}", tol=1e-4)
+        if heur:
+            pu.assert_grad_close(r.point_visibility, r2.point_visibility, "visibility", tol=1e-5)
+            pu.assert_grad_close(r.point_heuristic, r2.point_heuristic, "heuristic", tol=1e-4)
+
+
+def test_fused_frame_capacity_overflow_rerun():
+    from taichi_gaussian_rasterizer_amd import fused
+    size, n = (256, 192), 8000
+    cfg = RasterConfig()
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=1, seed=0)
+    cam = camera.to(device=DEV)
+    ref = gs.render_gaussians(g.to(DEV), cam, cfg, use_sh=True)
+    key = next(iter(k for k in fused._K_HINT if k[0] == n and k[1] == size[0]))
+    true_k, true_max = fused._K_HINT[key]
+    fused._K_HINT[key] = (true_k // 3, 8)  # poison the hints: the frame must detect the overflow and re-run,
+    again = gs.render_gaussians(g.to(DEV), cam, cfg, use_sh=True)  # and the catch-all sort must cover fuller tiles
+    assert torch.equal(again.image, ref.image) and fused._K_HINT[key][0] == true_k
