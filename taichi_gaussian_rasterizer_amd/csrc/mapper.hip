@@ -138,7 +138,7 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
     // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
     const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
     tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
-    cursors[i] = fits ? run : -1;
+    cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
     run += c;
   }
   if (t == 1023) {
@@ -347,8 +347,10 @@ __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid 
     const int c = s_cnt[e];
     if (c > 0) {
       const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
-      int* cur = cursors + gx + gy * a.tiles_wide;
-      s_base[e] = *cur < 0 ? -1 : atomicAdd(cur, c);  // -1: tile dropped by the capacity clamp
+      // a tile dropped by the capacity clamp has a hugely negative cursor: the returned value says so
+      // (no separate load in front of the atomic: the reservations of a workgroup must pipeline)
+      const int base = atomicAdd(cursors + gx + gy * a.tiles_wide, c);
+      s_base[e] = base < 0 ? -1 : base;
     }
     s_cnt[e] = 0;
   }
@@ -368,9 +370,8 @@ __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid 
           if (s_base[e] < 0) continue;
           slot = s_base[e] + atomicAdd(&s_cnt[e], 1);
         } else {
-          int* cur = cursors + gx + gy * a.tiles_wide;
-          if (*cur < 0) continue;
-          slot = atomicAdd(cur, 1);
+          slot = atomicAdd(cursors + gx + gy * a.tiles_wide, 1);
+          if (slot < 0) continue;
         }
         pairs[slot] = pair;
       }
