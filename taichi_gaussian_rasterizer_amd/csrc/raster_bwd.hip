@@ -131,10 +131,15 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
         // alpha*exp(-0.5 (tx^2+ty^2)) > thr  needs  tx^2+ty^2 < 2 ln(alpha/thr)
         const float r = sqrtf(2.0f * __logf(al / a.thr)) * 1.001f + 0.01f;
         const float et = 3.5f * (fabsf(Ax) + fabsf(Ay)) + r, eb = 3.5f * (fabsf(Bx) + fabsf(By)) + r;
+        // plus the image axes: the ellipse's bounding box against the sub-block
+        const float sx = p[4], sy = p[5];
+        const float ex = 3.5f + r * sqrtf(ax * ax * sx * sx + ay * ay * sy * sy);
+        const float ey = 3.5f + r * sqrtf(ay * ay * sx * sx + ax * ax * sy * sy);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const float cx = float(x0 + (b & 1) * 8) + 4.0f - mx, cy = float(y0 + (b >> 1) * 8) + 4.0f - my;
-          if (fabsf(cx * Ax + cy * Ay) <= et && fabsf(cx * Bx + cy * By) <= eb) mask |= 1 << b;
+          if (fabsf(cx * Ax + cy * Ay) <= et && fabsf(cx * Bx + cy * By) <= eb && fabsf(cx) <= ex && fabsf(cy) <= ey)
+            mask |= 1 << b;
         }
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
         const bool hit = alpha_raw > a.thr && Wt[b] < a.sat;  // backward.py:160,166
         if (__ballot(hit) == 0ull) continue;
         has_grad |= hit;
-        const float alc = fminf(alpha_raw, a.cmax);          // :169
+        const float alc = __builtin_amdgcn_fmed3f(alpha_raw, a.cmax, -1.0f);  // min(alpha, cmax), one v_med3_f32 (:169)
         const float T = 1.0f - Wt[b];
         const float w = hit ? alc * T : 0.0f;
         float dot = 0.0f;

@@ -100,13 +100,18 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
       if (!use_mask) {
         mask = (1 << NB) - 1;
       } else if (al > a.thr) {
+        // two separating-axis pairs: the ellipse's axes (sub-block projected into the ellipse frame) and
+        // the image axes (the ellipse's bounding box against the sub-block)
         const float r = sqrtf(__log2f(al / a.thr)) * 1.001f + 0.01f;
         const float et = 3.5f * (fabsf(Ax) + fabsf(Ay)) + r, eb = 3.5f * (fabsf(Bx) + fabsf(By)) + r;
+        const float rp = r * (1.0f / k_exp);  // the same radius in units of sigma
+        const float ex = 3.5f + rp * sqrtf(ax * ax * sx * sx + ay * ay * sy * sy);
+        const float ey = 3.5f + rp * sqrtf(ay * ay * sx * sx + ax * ax * sy * sy);
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           const float cx = float(x0 + (b & 1) * 8) + 4.0f - mx, cy = float(y0 + (b >> 1) * 8) + 4.0f - my;
           const float tc = cx * Ax + cy * Ay, bc = cx * Bx + cy * By;
-          if (fabsf(tc) <= et && fabsf(bc) <= eb) mask |= 1 << b;
+          if (fabsf(tc) <= et && fabsf(bc) <= eb && fabsf(cx) <= ex && fabsf(cy) <= ey) mask |= 1 << b;
         }
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
           const float tx = dx * g0v.z + dy * g0v.w, ty = dx * g1v.x + dy * g1v.y;
           p = gs_exp2_fast(-(tx * tx + ty * ty));
         }
-        const float al = fminf(g1v.z * p, a.cmax);  // forward.py:98-99
+        const float al = __builtin_amdgcn_fmed3f(g1v.z * p, a.cmax, -1.0f);  // min(alpha, cmax) (forward.py:98-99)
         bool hit = al > a.thr;
         if (FULL) hit = hit && !done[b];
         const float w = hit ? al * (1.0f - Wt[b]) : 0.0f;
