@@ -8,9 +8,10 @@
 //     upstream gradient, so each pixel carries ONE scalar R = sum_c rem_c * g_c instead of F
 //     channels:  R -= w * (f . g);  dL/dalpha = T (f . g) - R / (1 - alpha).
 //   * Lean kernel: the pdf gradients are linear in a few per-pixel moments, so each lane
-//     accumulates 9 sums (G, G tx, G ty, G tx^2, G ty^2, G tx dx, G tx dy, G ty dx, G ty dy with
-//     G = p * dL/dalpha) + F feature sums over its <= 4 pixels; the 7 splat gradients are formed
-//     from the wave totals once per splat, 64 splats at a time (one lane per splat).
+//     accumulates 6 sums in the ellipse frame (G, G tx, G ty, G tx^2, G tx ty, G ty^2 with
+//     G = p * dL/dalpha; tx, ty are O(1) so nothing cancels) + F feature sums over its <= 4 pixels;
+//     the 7 splat gradients are formed from the wave totals once per splat, 64 splats at a time
+//     (one lane per splat).
 //   * Wave reduction by fused v_add_f32_dpp (row_ror 8/4/2/1, row_bcast 15/31): a workgroup is
 //     exactly one wave64, so the whole-tile reduction needs no LDS atomics and no barrier
 //     (the reference: warp shuffle -> shared atomic -> global atomic, concurrent.py:81-85).
@@ -64,19 +65,20 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
   const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub) * region;
   if (x0 >= a.W || y0 >= a.H) return;
 
-  constexpr int NS = 9;                   // lean: 9 moment sums; full: 7 gradients + 2 heuristics
+  constexpr int NS = FULL ? 9 : 6;        // lean: 6 moment sums; full: 7 gradients + 2 heuristics
   constexpr int NACC = NS + FP;           // values reduced per splat
   constexpr int ROW = ((9 + FP + 15) / 16) * 16;
 
   // One LDS arena per wave.  The staged records (geo, feat) and the per-splat totals (acc) are dead
   // by the time the gradient rows (out) are written, so `out` aliases them: ~7.4 KB per wave
   // instead of ~11.5 KB, i.e. 21 instead of 13 resident waves per CU.
-  constexpr int GEO_F = 64 * 12, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
+  constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
+  constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
   constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
   constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
   __shared__ __attribute__((aligned(16))) float smem[ARENA_F];
   __shared__ int s_idx[64];
-  float4(*s_geo)[3] = reinterpret_cast<float4(*)[3]>(smem);
+  float4(*s_geo)[GEO_V4] = reinterpret_cast<float4(*)[GEO_V4]>(smem);
   float(*s_feat)[FP] = reinterpret_cast<float(*)[FP]>(smem + GEO_F);
   float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + GEO_F + FEAT_F);
   float(*s_out)[OUT_STRIDE] = reinterpret_cast<float(*)[OUT_STRIDE]>(smem);
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
       s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
-      s_geo[lane][2] = make_float4(ax, ay, isx, isy);
+      if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
       s_idx[lane] = idx;
       const float* f = a.features + int64_t(idx) * a.F;
 #pragma unroll
@@ -236,13 +238,12 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
           S[7] += aag * aag;                                  // :194-198
           S[8] += fabsf(aag * dmx) + fabsf(aag * dmy);
         } else {
+          // moments in the ellipse frame (tx, ty are O(1): no cancellation for elongated splats)
           const float G = p * alpha_grad;
           const float Gtx = G * tx, Gty = G * ty;
           S[0] += G;
           S[1] += Gtx; S[2] += Gty;
-          S[3] += Gtx * tx; S[4] += Gty * ty;
-          S[5] += Gtx * dx; S[6] += Gtx * dy;
-          S[7] += Gty * dx; S[8] += Gty * dy;
+          S[3] += Gtx * tx; S[4] += Gtx * ty; S[5] += Gty * ty;
         }
       }
 
@@ -280,12 +281,20 @@ __global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
           for (int c = 0; c < 7; ++c) row[c] = t[c];
           if (a.heur) { row[7 + FP] = t[7]; row[8 + FP] = t[8]; }
         } else {
+          // t = wave totals of (G, G tx, G ty, G tx^2, G tx ty, G ty^2), tx = d.axis/sx, ty = d.perp(axis)/sy.
+          // With d = (sx tx axis + sy ty perp(axis)) / |axis|^2 the position-weighted sums follow:
+          //   sum G tx d = (sx Mxx axis + sy Mxy perp) / n2 ,  sum G ty d = (sx Mxy axis + sy Myy perp) / n2
+          // and dp/dmean, dp/daxis, dp/dsigma (taichi_lib/generic.py:321-336) become
+          const float sx = 1.0f / isx, sy = 1.0f / isy;
+          const float in2 = 1.0f / (ax * ax + ay * ay);
+          const float txdx = (sx * ax * t[3] - sy * ay * t[4]) * in2, txdy = (sx * ay * t[3] + sy * ax * t[4]) * in2;
+          const float tydx = (sx * ax * t[4] - sy * ay * t[5]) * in2, tydy = (sx * ay * t[4] + sy * ax * t[5]) * in2;
           row[0] = al * (t[1] * isx * ax - t[2] * isy * ay);
           row[1] = al * (t[1] * isx * ay + t[2] * isy * ax);
-          row[2] = -al * (isx * t[5] + isy * t[8]);
-          row[3] = al * (isy * t[7] - isx * t[6]);
+          row[2] = -al * (isx * txdx + isy * tydy);
+          row[3] = al * (isy * tydx - isx * txdy);
           row[4] = al * t[3] * isx;
-          row[5] = al * t[4] * isy;
+          row[5] = al * t[5] * isy;
           row[6] = t[0];
         }
 #pragma unroll
