@@ -42,13 +42,18 @@ def _off(t: torch.Tensor, floats: int) -> ctypes.c_void_p:
 class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
-                image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool):
+                image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool,
+                strip=None, group=None):
         nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                           what="render_gaussians")
         lib = nv.lib()
         dev = position.device
         n = position.shape[0]
-        w, h = int(image_size[0]), int(image_size[1])
+        w, full_h = int(image_size[0]), int(image_size[1])
+        # tile-row strip of a sharded frame (parallel.py): projection and culling see the full image, the
+        # mapper and the rasterizer see a (w, y1-y0) image whose splats are shifted up by y0
+        y0, y1 = (0, full_h) if strip is None else (int(strip[0]), int(strip[1]))
+        h = y1 - y0
         C = feature.shape[1]
         degree = check_sh_degree(feature)
         F = C + (2 if render_depth else 0)
@@ -73,10 +78,10 @@ class _FusedRender(torch.autograd.Function):
         pscratch = torch.empty((max(pbytes, 1),), dtype=torch.uint8, device=dev)
         s = nv.stream()
         nv.check(lib.gs_project_fwd(n, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
-                                    nv.ptr(T), nv.ptr(proj), w, h, float(depth_range[0]), float(depth_range[1]), cfg,
-                                    nv.ptr(points), nv.ptr(depth), nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of),
-                                    nv.ptr(counts), nv.ptr(feats) if render_depth else None, F, nv.ptr(pscratch),
-                                    pbytes, s), "gs_project_fwd")
+                                    nv.ptr(T), nv.ptr(proj), w, full_h, float(depth_range[0]), float(depth_range[1]),
+                                    cfg, nv.ptr(points), nv.ptr(depth), nv.ptr(ndc), nv.ptr(indexes),
+                                    nv.ptr(slot_of), nv.ptr(counts), nv.ptr(feats) if render_depth else None, F,
+                                    float(y0), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
         nv.check(lib.gs_camera_position(nv.ptr(T), nv.ptr(cam_pos), s), "gs_camera_position")
         v_dev = nv.ptr(counts)
         nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
@@ -86,7 +91,7 @@ class _FusedRender(torch.autograd.Function):
         mbytes = lib.gs_map_scratch_bytes(n, num_tiles)
         mscratch = torch.empty((mbytes,), dtype=torch.uint8, device=dev)
         want_vis = config.compute_visibility or config.compute_point_heuristic
-        key = (n, w, h, ts, bool(use_depth16))
+        key = (n, w, full_h, y0, y1, ts, bool(use_depth16))
         hint = _K_HINT.get(key)
         k_cap = 0 if hint is None else int(hint[0] * 1.25) + 4096
         tile_hint = 0 if hint is None else -max(int(hint[1]), 1)  # sizing hint only; fuller tiles are still sorted
@@ -130,8 +135,8 @@ class _FusedRender(torch.autograd.Function):
         vis_out = vis[:V] if config.compute_visibility else empty
         heur = torch.zeros((V, 2), **f32) if config.compute_point_heuristic else torch.empty((0, 2), **f32)
 
-        ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, F=F, C=C, col0=col0, degree=degree, config=config,
-                        render_depth=render_depth)
+        ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, full_h=full_h, F=F, C=C, col0=col0, degree=degree, config=config,
+                        render_depth=render_depth, group=group, sharded=strip is not None)
         ctx.heur = heur
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
                               indexes, cam_pos, tile_ranges, o2p, image)
@@ -168,6 +173,15 @@ class _FusedRender(torch.autograd.Function):
             else:
                 extra_depth = g_depth.contiguous()
 
+        if m["sharded"]:
+            # every rank rendered a different strip: sum the per-Gaussian partial gradients with ONE
+            # all-reduce of the used columns (4*(7+F) bytes per visible Gaussian), then continue replicated
+            import torch.distributed as dist
+            packed = rows[:, :7 + F].contiguous()
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(m["group"]) > 1:
+                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=m["group"])
+            rows, RS = packed, 7 + F
+
         d_feature = torch.empty_like(feature)
         nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
                                nv.ptr(slot_of), nv.ptr(cam_pos), _off(rows, 7 + col0), RS, _off(feats, col0), F,
@@ -185,10 +199,11 @@ class _FusedRender(torch.autograd.Function):
         else:
             gd, gd2, gstride = nv.ptr(extra_depth), None, 1
         nv.check(lib.gs_project_bwd(n, V, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
-                                    nv.ptr(T), nv.ptr(proj), w, h, cfg, nv.ptr(slot_of), nv.ptr(rows), RS, gd, gd2,
+                                    nv.ptr(T), nv.ptr(proj), w, m["full_h"], cfg, nv.ptr(slot_of), nv.ptr(rows), RS, gd,
+                                    gd2,
                                     gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot), nv.ptr(d_al), nv.ptr(d_T),
                                     nv.ptr(d_proj), nv.ptr(scratch), nbytes, s), "gs_project_bwd")
-        return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None
+        return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
@@ -207,13 +222,16 @@ def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth:
     return True
 
 
-def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool):
+def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool,
+                 strip=None, group=None):
+    """strip=(y0, y1): render only those rows (a multiple-of-tile_size origin); `gaussians2d` of the result
+    then holds strip-local means (mean.y - y0).  See parallel.render_gaussians_sharded."""
     from .renderer import Rendering, compute_depth_variance
     image, alpha, g2d, depths, indexes, vis, heur = _FusedRender.apply(
         gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
         gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
         camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
-        use_depth16)
+        use_depth16, strip, group)
     indexes._gs_unique = True
     img_depth = img_var = None
     feature_image = image

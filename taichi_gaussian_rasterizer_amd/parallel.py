@@ -96,7 +96,6 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
     [y0, y1) of the full image (`rendering.strip == (y0, y1)`); after `.backward()` of a loss summed
     over strips, every rank holds the full parameter gradients."""
     from .renderer import Rendering, compute_depth_variance
-    ops = ops or default_ops()
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world_size is None:
@@ -104,6 +103,15 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
     w, h = (int(x) for x in camera_params.image_size)
     ts = config.tile_size
     y0, y1 = strip_pixels(rank, world_size, h, ts)
+
+    if ops is None:
+        from .fused import fused_supported, render_fused
+        if y1 > y0 and fused_supported(gaussians, camera_params, use_sh, False):
+            # the fused frame (fused.py) on this rank's strip; its backward carries the all-reduce
+            r = render_fused(gaussians, camera_params, config, render_depth, use_depth16, strip=(y0, y1), group=group)
+            object.__setattr__(r, "strip", (y0, y1))
+            return r
+        ops = default_ops()
 
     gaussians2d, depths, indexes, ndc_depths = ops.project_with_ndc(
         *gaussians.shape_tensors(), camera_params.T_camera_world, camera_params.projection,

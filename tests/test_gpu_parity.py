@@ -437,6 +437,13 @@ def test_sharded_strips_on_one_gpu(world):
     assert torch.equal(torch.cat(strips, 0), r.image.detach())
     for k, v in full.items():
         pu.assert_grad_close(sums[k], v.grad, f"summed partial grad {k}", tol=1e-4)
+    # the same with the composed operators (the path taken when the fused frame does not apply)
+    strips2 = []
+    for rank in range(world):
+        rr = parallel.render_gaussians_sharded(g.to(DEV), cam, cfg, use_sh=True, rank=rank, world_size=world,
+                                               ops=parallel.default_ops())
+        strips2.append(rr.image.detach())
+    assert torch.equal(torch.cat(strips2, 0), r.image.detach())
 
 
 # ------------------------------------------- full-size properties (BASELINE config 3 shapes)
