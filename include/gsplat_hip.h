@@ -213,6 +213,18 @@ int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const fl
 int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
                          float* grad_features, float* point_heuristic, void* stream);
 
+/* ------------------------------------------------------- depth / depth-variance epilogue --
+ * replaces: renderer.py:174-180 compute_depth_variance (+ the feature slice at :213-215) for
+ * render_depth=True.  image (P, 2+C) rasterized [z, z^2, features], alpha (P): depth = I0/(alpha+eps),
+ * depth_var = I1/(alpha+eps) - depth^2, features = I[2:].  Backward assembles grad_image (P, 2+C) from
+ * the three upstream gradients (any may be NULL = zero); alpha is non-differentiable.
+ */
+int gs_depth_split_fwd(int64_t pixels, int32_t channels, const float* image, const float* alpha, float eps,
+                       float* features, float* depth, float* depth_var, void* stream);
+int gs_depth_split_bwd(int64_t pixels, int32_t channels, const float* depth, const float* alpha, float eps,
+                       const float* grad_features, const float* grad_depth, const float* grad_depth_var,
+                       float* grad_image, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,68 @@
+// elementwise.hip -- per-pixel epilogue of render_depth=True (reference renderer.py:174-180, 213-215):
+//   depth = I0 / (W + eps),  depth_var = I1 / (W + eps) - depth^2,  features = I[2:]
+// where I is the rasterized (H,W,2+C) image of [z, z^2, features] and W the accumulated alpha.
+// One pass each way instead of the ~25 small torch kernels (slices, divisions, their backward
+// zero-fills and adds) the composed form costs.  HBM-bound: 4(F+1)P read, 4(C+2)P written.
+
+#include "gs_common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void depth_split_fwd_kernel(int64_t pixels, int C, const float* image,
+                                                              const float* alpha, float eps, float* feat,
+                                                              float* depth, float* var) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= pixels) return;
+  const int F = C + 2;
+  const float* px = image + i * F;
+  const float w = alpha[i] + eps;
+  const float d = px[0] / w;
+  depth[i] = d;
+  var[i] = px[1] / w - d * d;
+  for (int c = 0; c < C; ++c) feat[i * C + c] = px[2 + c];
+}
+
+// grad_image[...,0] = (g_depth - 2 depth g_var) / w ; [...,1] = g_var / w ; [...,2:] = g_feat
+// (image_weight is non-differentiable, rasterizer/function.py:72).  NULL upstream gradients are zeros.
+__global__ __launch_bounds__(256) void depth_split_bwd_kernel(int64_t pixels, int C, const float* depth,
+                                                              const float* alpha, float eps, const float* g_feat,
+                                                              const float* g_depth, const float* g_var,
+                                                              float* grad_image) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= pixels) return;
+  const int F = C + 2;
+  const float w = alpha[i] + eps;
+  const float gd = g_depth ? g_depth[i] : 0.0f, gv = g_var ? g_var[i] : 0.0f;
+  float* out = grad_image + i * F;
+  out[0] = (gd - 2.0f * depth[i] * gv) / w;
+  out[1] = gv / w;
+  for (int c = 0; c < C; ++c) out[2 + c] = g_feat ? g_feat[i * C + c] : 0.0f;
+}
+
+}  // namespace
+
+extern "C" int gs_depth_split_fwd(int64_t pixels, int32_t channels, const float* image, const float* alpha,
+                                  float eps, float* features, float* depth, float* depth_var, void* stream) {
+  GS_REQUIRE(channels >= 1 && channels + 2 <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED, "gs_depth_split_fwd: %d channels",
+             channels);
+  if (pixels == 0) return GS_OK;
+  GS_REQUIRE(image && alpha && features && depth && depth_var, GS_ERR_INVALID_ARGUMENT, "gs_depth_split_fwd: NULL buffer");
+  hipLaunchKernelGGL(depth_split_fwd_kernel, dim3(unsigned(gs_div_up(pixels, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pixels, channels, image, alpha, eps, features, depth, depth_var);
+  GS_CHECK_LAUNCH("gs_depth_split_fwd");
+  return GS_OK;
+}
+
+extern "C" int gs_depth_split_bwd(int64_t pixels, int32_t channels, const float* depth, const float* alpha,
+                                  float eps, const float* grad_features, const float* grad_depth,
+                                  const float* grad_depth_var, float* grad_image, void* stream) {
+  GS_REQUIRE(channels >= 1 && channels + 2 <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED, "gs_depth_split_bwd: %d channels",
+             channels);
+  if (pixels == 0) return GS_OK;
+  GS_REQUIRE(depth && alpha && grad_image, GS_ERR_INVALID_ARGUMENT, "gs_depth_split_bwd: NULL buffer");
+  hipLaunchKernelGGL(depth_split_bwd_kernel, dim3(unsigned(gs_div_up(pixels, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), pixels, channels, depth, alpha, eps, grad_features, grad_depth,
+                     grad_depth_var, grad_image);
+  GS_CHECK_LAUNCH("gs_depth_split_bwd");
+  return GS_OK;
+}

@@ -476,19 +476,32 @@ __device__ __forceinline__ void rank_sort_rows(const uint64_t* s_key, const uint
 // compares, not 8.
 template <int RMAX>
 __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const int2* tile_ranges,
-                                                            const uint64_t* pairs, int* o2p, uint64_t* keys_out,
-                                                            int depth16) {
+                                                            uint64_t* pairs, int* o2p, uint64_t* keys_out,
+                                                            int depth16, int skip_full) {
   __shared__ uint64_t s_key[64 * RMAX];
   const int tile = gs_xcd_remap(blockIdx.x, num_tiles);
   if (tile < 0) return;
   const int2 r = tile_ranges[tile];
   const int n = r.y - r.x;
-  if (n <= 0 || n > 64 * RMAX) return;  // fuller tiles belong to the bitonic kernel
-  const uint64_t* seg = pairs + r.x;
+  if (n <= 0) return;
   const int lane = threadIdx.x;
+  const int shift = depth16 ? 16 : 32;
+  if (n > 64 * RMAX) {
+    if (skip_full) return;  // a dedicated bitonic launch follows for these
+    // fuller than this launch was sized for (only when the caller's hint was low): this wave sorts the
+    // bucket in place in global memory -- slow, rare, and never wrong
+    uint64_t* gseg = pairs + r.x;
+    bitonic_sort<64>(gseg, n, lane);
+    for (int i = lane; i < n; i += 64) {
+      const uint64_t kv = gseg[i];
+      o2p[r.x + i] = int(uint32_t(kv));
+      if (keys_out) keys_out[r.x + i] = (kv >> 32) | (uint64_t(uint32_t(tile)) << shift);
+    }
+    return;
+  }
+  const uint64_t* seg = pairs + r.x;
   for (int i = lane; i < n; i += 64) s_key[i] = seg[i];
   __syncthreads();
-  const int shift = depth16 ? 16 : 32;
   if (n <= 64) rank_sort_rows<1>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
   else if (n <= 128) rank_sort_rows<2>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
   else if (n <= 256) rank_sort_rows<4>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
@@ -734,28 +747,28 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
   const int grid = 8 * int(gs_div_up(num_tiles, 8));
   const int2* r = reinterpret_cast<const int2*>(tile_ranges);
   // max_tile_count > 0: exact population of the fullest tile (read back by the caller);
-  // max_tile_count <= 0: unknown -- |max_tile_count| is a hint (0 = none).  The rank sort is sized from
-  // it and a small persistent bitonic launch catches any fuller tile, so a wrong hint costs time only.
+  // max_tile_count <= 0: unknown -- |max_tile_count| is a hint (0 = none).  A wrong hint costs time only.
   const bool exact = max_tile_count > 0;
   const int guess = exact ? max_tile_count : (max_tile_count < 0 ? -max_tile_count : 1024);
+  // tiles fuller than the rank sort covers go to a dedicated bitonic launch when such tiles are known or
+  // expected; otherwise (a hint that turns out low) the rank-sort wave sorts them itself, slowly
+  const bool bitonic_pass = guess > 1024;
+  const int skip_full = (exact || bitonic_pass) ? 1 : 0;
   int covered;
   if (guess <= 256) {
     covered = 256;
     hipLaunchKernelGGL((tile_rank_sort_kernel<4>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
-                       sorted_keys, use_depth16);
+                       sorted_keys, use_depth16, skip_full);
   } else if (guess <= 512) {
     covered = 512;
     hipLaunchKernelGGL((tile_rank_sort_kernel<8>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
-                       sorted_keys, use_depth16);
+                       sorted_keys, use_depth16, skip_full);
   } else {
     covered = 1024;
     hipLaunchKernelGGL((tile_rank_sort_kernel<16>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs,
-                       overlap_to_point, sorted_keys, use_depth16);
+                       overlap_to_point, sorted_keys, use_depth16, skip_full);
   }
-  if (!exact)
-    hipLaunchKernelGGL((tile_sort_kernel<1024, 8192>), dim3(min(num_tiles, 256)), dim3(1024), 0, s, num_tiles, r, pairs,
-                       overlap_to_point, sorted_keys, use_depth16, covered);
-  else if (max_tile_count > covered)
+  if (bitonic_pass)
     hipLaunchKernelGGL((tile_sort_kernel<1024, 8192>), dim3(min(num_tiles, 2048)), dim3(1024), 0, s, num_tiles, r,
                        pairs, overlap_to_point, sorted_keys, use_depth16, covered);
   GS_CHECK_LAUNCH("gs_map_finish/sort");

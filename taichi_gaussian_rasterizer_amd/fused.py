@@ -130,6 +130,17 @@ class _FusedRender(torch.autograd.Function):
             ready.synchronize()
         _K_HINT[key] = (max(K, hint[0]) if hint else K, max(max_tile, hint[1]) if hint else max_tile)
 
+        # render_depth: per-pixel epilogue (depth, depth variance, feature slice) in one pass
+        img_depth = img_var = None
+        out_image = image
+        if render_depth:
+            out_image = torch.empty((h, w, C), **f32)
+            img_depth, img_var = torch.empty((h, w), **f32), torch.empty((h, w), **f32)
+            nv.check(lib.gs_depth_split_fwd(h * w, C, nv.ptr(image), nv.ptr(alpha), 1e-6, nv.ptr(out_image),
+                                            nv.ptr(img_depth), nv.ptr(img_var), s), "gs_depth_split_fwd")
+        else:
+            img_depth = img_var = torch.empty((0,), **f32)
+
         points_v, depth_v, indexes_v = points[:V], depth[:V], indexes[:V]
         empty = torch.empty((0,), **f32)
         vis_out = vis[:V] if config.compute_visibility else empty
@@ -139,14 +150,16 @@ class _FusedRender(torch.autograd.Function):
                         render_depth=render_depth, group=group, sharded=strip is not None)
         ctx.heur = heur
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
-                              indexes, cam_pos, tile_ranges, o2p, image)
+                              indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth)
         ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur)
-        return image, alpha, points_v, depth_v, indexes_v, vis_out, heur
+        if not render_depth:
+            ctx.mark_non_differentiable(img_depth, img_var)
+        return out_image, alpha, points_v, depth_v, indexes_v, vis_out, heur, img_depth, img_var
 
     @staticmethod
-    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur):
+    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var):
         (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
-         tile_ranges, o2p, image) = ctx.saved_tensors
+         tile_ranges, o2p, image, alpha, img_depth) = ctx.saved_tensors
         m = ctx.meta
         lib = nv.lib()
         dev = position.device
@@ -156,6 +169,15 @@ class _FusedRender(torch.autograd.Function):
         s = nv.stream()
         RS = lib.gs_grad_row_floats(F)
         rows = torch.zeros((max(V, 1), RS), dtype=torch.float32, device=dev)
+        if m["render_depth"] and V > 0 and any(g is not None for g in (g_image, g_img_depth, g_img_var)):
+            # assemble the gradient of the rasterized (H,W,2+C) image from the three upstream gradients
+            gf_ = g_image.contiguous() if g_image is not None else None
+            gd_ = g_img_depth.contiguous() if g_img_depth is not None else None
+            gv_ = g_img_var.contiguous() if g_img_var is not None else None
+            nv.require_device(gf_, gd_, gv_, what="render_gaussians backward")
+            g_image = torch.empty((h, w, F), dtype=torch.float32, device=dev)
+            nv.check(lib.gs_depth_split_bwd(h * w, C, nv.ptr(img_depth), nv.ptr(alpha), 1e-6, nv.ptr(gf_), nv.ptr(gd_),
+                                            nv.ptr(gv_), nv.ptr(g_image), s), "gs_depth_split_bwd")
         if g_image is not None and V > 0:
             gi = g_image.contiguous()
             nv.require_device(gi, what="render_gaussians backward")
@@ -227,18 +249,15 @@ def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: b
     """strip=(y0, y1): render only those rows (a multiple-of-tile_size origin); `gaussians2d` of the result
     then holds strip-local means (mean.y - y0).  See parallel.render_gaussians_sharded."""
     from .renderer import Rendering, compute_depth_variance
-    image, alpha, g2d, depths, indexes, vis, heur = _FusedRender.apply(
+    image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var = _FusedRender.apply(
         gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
         gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
         camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
         use_depth16, strip, group)
     indexes._gs_unique = True
-    img_depth = img_var = None
-    feature_image = image
-    if render_depth:
-        img_depth, img_var = compute_depth_variance(image[..., :2], alpha)
-        feature_image = image[..., 2:]
-    return Rendering(image=feature_image, image_weight=alpha, depth=img_depth, depth_var=img_var,
+    if not render_depth:
+        img_depth = img_var = None
+    return Rendering(image=image, image_weight=alpha, depth=img_depth, depth_var=img_var,
                      camera=camera_params, config=config,
                      point_visibility=vis if config.compute_visibility else None,
                      point_heuristic=heur if config.compute_point_heuristic else None,

@@ -547,3 +547,48 @@ def test_fused_frame_capacity_overflow_rerun():
     fused._K_HINT[key] = (true_k // 3, 8)  # poison the hints: the frame must detect the overflow and re-run,
     again = gs.render_gaussians(g.to(DEV), cam, cfg, use_sh=True)  # and the catch-all sort must cover fuller tiles
     assert torch.equal(again.image, ref.image) and fused._K_HINT[key][0] == true_k
+
+
+# ----------------------------------------------- remaining render_gaussians options (a15)
+def test_render_gaussians_plain_features_median_depth_depth16_antialias():
+    """use_sh=False (feature gather), render_median_depth (second, non-blending raster pass,
+    renderer.py:203-208), use_depth16 keys (tile_mapper.py:47-64) and the antialiased pdf through the
+    composed operators, against the oracle fed the same projected splats."""
+    size, n = (160, 112), 4000
+    torch.manual_seed(5)
+    camera = scenes.benchmark_camera(size)
+    g = scenes.random_3d_gaussians(n, camera, scale_factor=1.5, margin=0.1)
+    cam = camera.to(device=DEV)
+    for cfg, depth16 in ((RasterConfig(), False), (RasterConfig(), True), (RasterConfig(antialias=True, blur_cov=0.0), False)):
+        gd = g.to(DEV).requires_grad_(True)
+        r = gs.render_gaussians(gd, cam, cfg, use_sh=False, render_depth=True, use_depth16=depth16,
+                                render_median_depth=True)
+        ocfg = orc.OracleConfig.of(cfg)
+        p_np, d_np = pu.to_np(r.gaussians2d), pu.to_np(r.point_depth)
+        idx = pu.to_np(r.points_in_view)
+        ndc = orc.ndc_depth(d_np, camera.near_plane, camera.far_plane)
+        o2p, ranges = orc.map_to_tiles(p_np, ndc, size, ocfg, depth16)
+        feats = np.concatenate([d_np, d_np ** 2, g.feature.numpy()[idx]], 1).astype(np.float32)
+        image_ref, alpha_ref, _ = orc.rasterize_with_tiles(p_np, feats, o2p, ranges, size, ocfg)
+        tol = dict(atol=2e-4, rtol=2e-4) if cfg.antialias else {}
+        pu.assert_pixels_close(r.image, image_ref[..., 2:], "image", **tol)
+        pu.assert_pixels_close(r.image_weight, alpha_ref, "weight", **tol)
+        w = alpha_ref + np.float32(1e-6)
+        pu.assert_pixels_close(r.depth, image_ref[..., 0] / w, "depth", atol=1e-3, rtol=1e-3)
+        import dataclasses
+        mcfg = orc.OracleConfig.of(dataclasses.replace(cfg, use_alpha_blending=False, saturate_threshold=0.5))
+        med_ref, _, _ = orc.rasterize_with_tiles(p_np, d_np, o2p, ranges, size, mcfg)
+        assert r.median_depth.shape == (size[1], size[0])
+        pu.assert_pixels_close(r.median_depth, med_ref[..., 0], "median depth", atol=1e-4, rtol=1e-4)
+        (r.image.sum() + r.depth.sum()).backward()
+        assert gd.feature.grad.shape == g.feature.shape and bool(torch.isfinite(gd.position.grad).all())
+        assert float(gd.feature.grad.abs().sum()) > 0
+
+
+def test_float64_and_cpu_inputs_are_rejected_not_emulated():
+    g, camera = scenes.benchmark_scene(100, (64, 64), sh_degree=1)
+    cam = camera.to(device=DEV)
+    with pytest.raises(TypeError, match="float32"):
+        gs.render_gaussians(g.to(DEV).to(dtype=torch.float64), cam.to(dtype=torch.float64), RasterConfig(), use_sh=True)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        gs.render_gaussians(g, cam, RasterConfig(), use_sh=True)
