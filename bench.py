@@ -71,12 +71,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+    # GS_BENCH_BACKEND=gloo + GS_BENCH_SHARE_GPU=1: rehearsal of the multi-rank code path on a one-GPU box
+    # (all ranks on cuda:0, collectives staged through the host); never used for reported numbers
+    backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
+    if os.environ.get("GS_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path in the product"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import taichi_gaussian_rasterizer_amd as gs
     from taichi_gaussian_rasterizer_amd import _native as nv
@@ -195,7 +203,7 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" or world == 1 else f"synthetic (REHEARSAL: backend {backend}, ranks share one GPU)",
             "config": {"workload": f"{args.workload}: {wl['n']} Gaussians, {W}x{H}, SH deg {wl['sh_degree']}, "
                                    f"tile 16, {'fwd+bwd' if wl['backward'] else 'fwd'}"
                                    f"{', depth features' if wl['depth'] else ''}",
