@@ -53,8 +53,12 @@ __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, f
   ds_dsig = ds_dx * -z;
 }
 
+#ifndef GS_BWD_WAVES
+#define GS_BWD_WAVES 1  // minimum waves per SIMD requested from the register allocator (1 = no constraint)
+#endif
+
 template <int NB, int FP, bool FULL>
-__global__ __launch_bounds__(64) void raster_bwd_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
   const int item = gs_xcd_remap(blockIdx.x, a.num_items);
   if (item < 0) return;
   const int lane = threadIdx.x;
