@@ -161,18 +161,25 @@ __global__ __launch_bounds__(256) void sh_bwd_kernel(int64_t v, int C, const flo
 // (slot_of, N entries, -1 = culled) is known.  One lane per Gaussian writes its whole gradient row --
 // zeros for culled Gaussians -- so the (N,C,D) gradient is produced in a single pass with no memset
 // and no atomics.
-template <int DEG>
+// STAGED (C*D = 48 floats, i.e. RGB at degree 3): gradient rows are staged in LDS and written out
+// as contiguous 12-KiB tiles per wave.
+template <int DEG, bool STAGED>
 __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, const float* params,
                                                            const float* positions, const int* slot_of,
                                                            const float* cam, const float* gout, int gout_stride,
                                                            const float* fwd_out, int fwd_out_stride,
                                                            float* d_params, float* d_positions, float* d_cam) {
   constexpr int D = (DEG + 1) * (DEG + 1);
+  constexpr int TILE_STRIDE = 48 + 4;  // floats per staged row (+16 B: conflict-free, still 16-B aligned)
+  __shared__ __attribute__((aligned(16))) float s_tile[STAGED ? 4 : 1][STAGED ? 64 * TILE_STRIDE : 1];
   const int64_t idx = int64_t(blockIdx.x) * 256 + threadIdx.x;
   float gd[3] = {0, 0, 0};
   if (idx < n) {
     const int slot = slot_of[idx];
-    if (slot < 0) {
+    if (slot < 0 && STAGED) {
+      float* trow = s_tile[threadIdx.x >> 6] + (threadIdx.x & 63) * TILE_STRIDE;
+      for (int e = 0; e < C * D; ++e) trow[e] = 0.0f;
+    } else if (slot < 0) {
       for (int c = 0; c < C; ++c) {
         float* drow = d_params + (idx * C + c) * D;
         if ((D & 3) == 0) {
@@ -212,15 +219,23 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
 #pragma unroll
           for (int d = 0; d < D; ++d) w[d] += g * row[d];
         }
-        float* drow = d_params + (idx * C + c) * D;
-        if ((D & 3) == 0) {
-          float4* d4 = reinterpret_cast<float4*>(drow);
+        if (STAGED) {
+          // row goes to the wave's LDS tile; the whole 64-row tile is stored afterwards with fully
+          // coalesced 1-KiB wave stores (a lane-per-row store touches 64 different lines per instruction)
+          float* trow = s_tile[threadIdx.x >> 6] + (threadIdx.x & 63) * TILE_STRIDE + c * D;
 #pragma unroll
-          for (int k = 0; k < D / 4; ++k)
-            d4[k] = make_float4(g * Y[4 * k], g * Y[4 * k + 1], g * Y[4 * k + 2], g * Y[4 * k + 3]);
+          for (int d = 0; d < D; ++d) trow[d] = g * Y[d];
         } else {
+          float* drow = d_params + (idx * C + c) * D;
+          if ((D & 3) == 0) {
+            float4* d4 = reinterpret_cast<float4*>(drow);
 #pragma unroll
-          for (int d = 0; d < D; ++d) drow[d] = g * Y[d];
+            for (int k = 0; k < D / 4; ++k)
+              d4[k] = make_float4(g * Y[4 * k], g * Y[4 * k + 1], g * Y[4 * k + 2], g * Y[4 * k + 3]);
+          } else {
+#pragma unroll
+            for (int d = 0; d < D; ++d) drow[d] = g * Y[d];
+          }
         }
       }
       if (DEG >= 1 && (d_positions || d_cam)) {
@@ -233,6 +248,18 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
       }
     }
     if (d_positions) { d_positions[3 * idx] = gd[0]; d_positions[3 * idx + 1] = gd[1]; d_positions[3 * idx + 2] = gd[2]; }
+  }
+  if (STAGED) {
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t row0 = int64_t(blockIdx.x) * 256 + wave * 64;  // first Gaussian of this wave
+    const int64_t rows = n - row0 < 64 ? n - row0 : 64;
+    float4* dst = reinterpret_cast<float4*>(d_params + row0 * 48);
+    for (int k = 0; k < 12; ++k) {
+      const int e = k * 64 + lane;           // float4 index inside the 64 x 12 tile
+      const int r = e / 12, q = e - r * 12;
+      if (r < rows) dst[e] = *reinterpret_cast<const float4*>(s_tile[wave] + r * TILE_STRIDE + q * 4);
+    }
   }
   if (d_cam && DEG >= 1) {
     __shared__ float s_part[4][3];
@@ -297,14 +324,20 @@ extern "C" int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree,
     }
     const dim3 grid(unsigned(gs_div_up(n, 256))), block(256);
 #define SH_DENSE(DEG)                                                                                               \
-  hipLaunchKernelGGL((sh_bwd_dense_kernel<DEG>), grid, block, 0, s, n, channels, params, positions, slot_of,        \
+  hipLaunchKernelGGL((sh_bwd_dense_kernel<DEG, false>), grid, block, 0, s, n, channels, params, positions, slot_of, \
                      camera_pos, grad_out, grad_out_stride, fwd_out, fwd_out_stride > 0 ? fwd_out_stride : channels,   \
                      d_params, d_positions, d_camera_pos)
-    switch (degree) {
-      case 0: SH_DENSE(0); break;
-      case 1: SH_DENSE(1); break;
-      case 2: SH_DENSE(2); break;
-      default: SH_DENSE(3); break;
+    if (degree == 3 && channels == 3) {
+      hipLaunchKernelGGL((sh_bwd_dense_kernel<3, true>), grid, block, 0, s, n, channels, params, positions, slot_of,
+                         camera_pos, grad_out, grad_out_stride, fwd_out, fwd_out_stride > 0 ? fwd_out_stride : channels,
+                         d_params, d_positions, d_camera_pos);
+    } else {
+      switch (degree) {
+        case 0: SH_DENSE(0); break;
+        case 1: SH_DENSE(1); break;
+        case 2: SH_DENSE(2); break;
+        default: SH_DENSE(3); break;
+      }
     }
     GS_CHECK_LAUNCH("gs_sh_bwd/dense");
     return GS_OK;
