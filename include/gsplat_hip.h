@@ -148,12 +148,13 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  * past it are dropped and counts_out[2] is set to 1 so that the caller can retry with more room;
  * counts_out is int32[4] = {K, fullest tile, overflow flag, 0}; max_tile_count <= 0 in
  * gs_map_finish means "not read back": its magnitude is only a hint for sizing the per-tile sort
- * (0 = no hint) and a catch-all launch sorts any fuller tile.
+ * (0 = no hint); fuller tiles are still sorted.  tile_order (optional, T int32) receives the tiles by
+ * descending population: a launch order for gs_raster_fwd / gs_raster_bwd (heaviest tiles first).
  */
 int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
-                   void* scratch, int64_t scratch_bytes, void* stream);
+                   int32_t* tile_order, void* scratch, int64_t scratch_bytes, void* stream);
 int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_count, const float* points,
                   const float* depth, int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
                   const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys, void* pair_scratch,
@@ -191,11 +192,13 @@ int gs_find_ranges(int64_t k, const uint64_t* sorted_keys, int32_t use_depth16, 
  * rasterizer/function.py:43-76).  points (V,7), features (V,F), tile_ranges (T,2) int32 with
  * T = ceil(W/ts)*ceil(H/ts), overlap_to_point (K) int32.  image (H,W,F), alpha (H,W).
  * visibility (V) must be zero-filled by the caller when cfg->compute_visibility, else may be NULL.
+ * tile_order (optional, T int32, a permutation of the tile ids, from gs_map_prepare): launch order;
+ * NULL = XCD-contiguous bands.  Results do not depend on it.
  */
 int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
                   const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                  int32_t height, const GsRasterConfig* cfg, float* image, float* alpha, float* visibility,
-                  void* stream);
+                  int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, float* image, float* alpha,
+                  float* visibility, void* stream);
 
 /* replaces: rasterizer/backward.py:53-228 _backward_kernel.
  * Per-Gaussian gradients are accumulated with float atomics into ONE row per Gaussian,
@@ -208,8 +211,8 @@ int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const fl
 int32_t gs_grad_row_floats(int32_t num_features);
 int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
                   const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                  int32_t height, const GsRasterConfig* cfg, const float* image, const float* grad_image,
-                  float* grad_rows, void* stream);
+                  int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const float* image,
+                  const float* grad_image, float* grad_rows, void* stream);
 int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
                          float* grad_features, float* point_heuristic, void* stream);
 

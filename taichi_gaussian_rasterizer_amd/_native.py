@@ -45,7 +45,7 @@ SIGNATURES = {
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
                                   _P]),
     "gs_map_scratch_bytes": (_I64, [_I64, _I64]),
-    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _I64, _P]),
+    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _P, _I64,
                                       _P]),
     "gs_tile_count": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P]),
@@ -55,9 +55,9 @@ SIGNATURES = {
     "gs_sort_scratch_bytes": (_I64, [_I64, _I32]),
     "gs_radix_sort_pairs": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, _P]),
     "gs_find_ranges": (ctypes.c_int, [_I64, _P, _I32, _I64, _P, _P]),
-    "gs_raster_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P]),
+    "gs_raster_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P]),
     "gs_grad_row_floats": (_I32, [_I32]),
-    "gs_raster_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P]),
+    "gs_raster_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P]),
     "gs_raster_bwd_unpack": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _P]),
     "gs_depth_split_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P]),
     "gs_depth_split_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P, _P]),

@@ -149,6 +149,33 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   }
 }
 
+// Launch order for the rasterizer: tiles by descending population (counting sort on min(count, 1023)).
+// The order inside a bin comes from LDS atomics and is arbitrary; it only affects scheduling.
+__global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const int* tile_hist, int* tile_order) {
+  __shared__ int s_bin[1024];
+  __shared__ int s_scan[1024];
+  const int t = threadIdx.x;
+  s_bin[t] = 0;
+  __syncthreads();
+  for (int i = t; i < num_tiles; i += 1024) atomicAdd(&s_bin[min(tile_hist[i], 1023)], 1);
+  __syncthreads();
+  // start of bin b in descending order = number of tiles in bins above b: suffix scan
+  s_scan[t] = s_bin[1023 - t];
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int x = s_scan[t];
+    if (t >= off) x += s_scan[t - off];
+    __syncthreads();
+    s_scan[t] = x;
+    __syncthreads();
+  }
+  const int start = s_scan[t] - s_bin[1023 - t];  // exclusive, for bin 1023 - t
+  __syncthreads();
+  s_bin[1023 - t] = start;
+  __syncthreads();
+  for (int i = t; i < num_tiles; i += 1024) tile_order[atomicAdd(&s_bin[min(tile_hist[i], 1023)], 1)] = i;
+}
+
 // ---- region-binned counting / bucketing --------------------------------------------------
 // Scattered 4-byte global atomics run at only ~20 G/s on MI355X (every one is its own 64-B
 // memory-side request), which made the plain count / emit kernels above atomic-bound (K atomics
@@ -679,7 +706,8 @@ extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
 
 extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                               const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges,
-                              int32_t* counts_out, void* scratch, int64_t scratch_bytes, void* stream) {
+                              int32_t* counts_out, int32_t* tile_order, void* scratch, int64_t scratch_bytes,
+                              void* stream) {
   MapArgs a;
   if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0)) return rc;
   a.v_dev = v_dev;
@@ -717,6 +745,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   }
   hipLaunchKernelGGL(map_scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist,
                      reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity);
+  if (tile_order) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist, tile_order);
   GS_CHECK_LAUNCH("gs_map_prepare/scan");
   return GS_OK;
 }

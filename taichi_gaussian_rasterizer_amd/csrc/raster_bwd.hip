@@ -40,6 +40,7 @@ struct BwdArgs {
   int tile_size;
   int sub;
   int num_items;
+  const int* tile_order;  // optional launch order of the items (heaviest first)
   float cmax, thr, sat;
   int aa, heur;
 };
@@ -59,10 +60,18 @@ __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, f
 
 template <int NB, int FP, bool FULL>
 __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
-  const int item = gs_xcd_remap(blockIdx.x, a.num_items);
-  if (item < 0) return;
-  const int lane = threadIdx.x;
+  // launch order: heaviest tiles first when the mapper supplied an order (shortens the tail of the
+  // launch: a tile's cost is proportional to its splat count), else XCD-contiguous bands
   const int per_tile = a.sub * a.sub;
+  int item;
+  if (a.tile_order) {
+    if (int(blockIdx.x) >= a.num_items) return;
+    item = a.tile_order[blockIdx.x / per_tile] * per_tile + blockIdx.x % per_tile;
+  } else {
+    item = gs_xcd_remap(blockIdx.x, a.num_items);
+    if (item < 0) return;
+  }
+  const int lane = threadIdx.x;
   const int tile = item / per_tile, quad = item - tile * per_tile;
   const int region = NB == 1 ? 8 : 16;
   const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub) * region;
@@ -352,8 +361,8 @@ extern "C" int32_t gs_grad_row_floats(int32_t num_features) { return int32_t(gs_
 
 extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
                              const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                             int32_t height, const GsRasterConfig* cfg, const float* image, const float* grad_image,
-                             float* grad_rows, void* stream) {
+                             int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const float* image,
+                             const float* grad_image, float* grad_rows, void* stream) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_bwd: image size %dx%d", width, height);
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
@@ -374,6 +383,7 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.tile_size = ts;
   a.sub = ts == 32 ? 2 : 1;
   a.num_items = a.tiles_wide * int(gs_div_up(height, ts)) * a.sub * a.sub;
+  a.tile_order = tile_order;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -36,7 +36,8 @@ struct FwdArgs {
   int tiles_wide;
   int tile_size;
   int sub;        // 16x16 regions per tile side (1, or 2 at tile_size 32)
-  int num_items;  // tiles * sub * sub
+  int num_items;
+  const int* tile_order;  // optional launch order of the items (heaviest first)  // tiles * sub * sub
   float cmax, thr, sat_level;
   int blend, vis, aa;
 };
@@ -51,10 +52,18 @@ __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
 // quantile mode / visibility / antialias (the common blend-only case gets its own lean kernel).
 template <int NB, int FP, bool FULL>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
-  const int item = gs_xcd_remap(blockIdx.x, a.num_items);
-  if (item < 0) return;
-  const int lane = threadIdx.x;
+  // launch order: heaviest tiles first when the mapper supplied an order (shortens the tail of the
+  // launch: a tile's cost is proportional to its splat count), else XCD-contiguous bands
   const int per_tile = a.sub * a.sub;
+  int item;
+  if (a.tile_order) {
+    if (int(blockIdx.x) >= a.num_items) return;
+    item = a.tile_order[blockIdx.x / per_tile] * per_tile + blockIdx.x % per_tile;
+  } else {
+    item = gs_xcd_remap(blockIdx.x, a.num_items);
+    if (item < 0) return;
+  }
+  const int lane = threadIdx.x;
   const int tile = item / per_tile, quad = item - tile * per_tile;
   const int region = NB == 1 ? 8 : 16;
   const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub) * region;
@@ -225,8 +234,8 @@ int launch_fp(const FwdArgs& a, hipStream_t s) {
 
 extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
                              const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                             int32_t height, const GsRasterConfig* cfg, float* image, float* alpha,
-                             float* visibility, void* stream) {
+                             int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, float* image,
+                             float* alpha, float* visibility, void* stream) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_fwd: image size %dx%d", width, height);
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
@@ -245,6 +254,7 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   a.tile_size = ts;
   a.sub = ts == 32 ? 2 : 1;
   a.num_items = a.tiles_wide * int(gs_div_up(height, ts)) * a.sub * a.sub;
+  a.tile_order = tile_order;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;

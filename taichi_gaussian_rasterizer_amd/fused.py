@@ -88,6 +88,7 @@ class _FusedRender(torch.autograd.Function):
                                nv.ptr(cam_pos), _off(feats, col0), F, s), "gs_sh_fwd")
 
         tile_ranges = torch.empty((*tile_shape, 2), dtype=torch.int32, device=dev)
+        tile_order = torch.empty((num_tiles,), dtype=torch.int32, device=dev)  # heaviest tiles first
         mbytes = lib.gs_map_scratch_bytes(n, num_tiles)
         mscratch = torch.empty((mbytes,), dtype=torch.uint8, device=dev)
         want_vis = config.compute_visibility or config.compute_point_heuristic
@@ -100,7 +101,8 @@ class _FusedRender(torch.autograd.Function):
 
         def map_and_raster(k_cap):
             nv.check(lib.gs_map_prepare(n, v_dev, nv.ptr(points), w, h, cfg, k_cap, nv.ptr(tile_ranges),
-                                        _off(counts, 4), nv.ptr(mscratch), mbytes, s), "gs_map_prepare")
+                                        _off(counts, 4), nv.ptr(tile_order), nv.ptr(mscratch), mbytes, s),
+                     "gs_map_prepare")
             # V, K and the overflow flag are final here: copy them out asynchronously and keep enqueueing;
             # the host waits on this event while the sort and the rasterizer are still running
             host_counts.copy_(counts, non_blocking=True)
@@ -118,7 +120,8 @@ class _FusedRender(torch.autograd.Function):
             alpha = torch.empty((h, w), **f32)
             vis = torch.zeros((n,), **f32) if want_vis else None
             nv.check(lib.gs_raster_fwd(n, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), k_cap,
-                                       w, h, cfg, nv.ptr(image), nv.ptr(alpha), nv.ptr(vis), s), "gs_raster_fwd")
+                                       w, h, cfg, nv.ptr(tile_order), nv.ptr(image), nv.ptr(alpha), nv.ptr(vis), s),
+                     "gs_raster_fwd")
             return o2p, image, alpha, vis
 
         o2p, image, alpha, vis = map_and_raster(k_cap)
@@ -150,7 +153,7 @@ class _FusedRender(torch.autograd.Function):
                         render_depth=render_depth, group=group, sharded=strip is not None)
         ctx.heur = heur
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
-                              indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth)
+                              indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth, tile_order)
         ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur)
         if not render_depth:
             ctx.mark_non_differentiable(img_depth, img_var)
@@ -159,7 +162,7 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var):
         (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
-         tile_ranges, o2p, image, alpha, img_depth) = ctx.saved_tensors
+         tile_ranges, o2p, image, alpha, img_depth, tile_order) = ctx.saved_tensors
         m = ctx.meta
         lib = nv.lib()
         dev = position.device
@@ -182,7 +185,8 @@ class _FusedRender(torch.autograd.Function):
             gi = g_image.contiguous()
             nv.require_device(gi, what="render_gaussians backward")
             nv.check(lib.gs_raster_bwd(V, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), K, w, h,
-                                       cfg, nv.ptr(image), nv.ptr(gi), nv.ptr(rows), s), "gs_raster_bwd")
+                                       cfg, nv.ptr(tile_order), nv.ptr(image), nv.ptr(gi), nv.ptr(rows), s),
+                     "gs_raster_bwd")
         if config.compute_point_heuristic and V > 0:
             ctx.heur.copy_(rows[:V, 7 + F:9 + F])
         # gradients a caller attached to the projected splats / depths themselves (e.g. a regulariser)

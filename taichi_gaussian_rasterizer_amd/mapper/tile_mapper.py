@@ -67,7 +67,7 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
     counts = torch.empty((4,), dtype=torch.int32, device=dev)
     nbytes = lib.gs_map_scratch_bytes(v, num_tiles)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-    nv.check(lib.gs_map_prepare(v, None, nv.ptr(g), w, h, cfg, 0, nv.ptr(tile_ranges), nv.ptr(counts),
+    nv.check(lib.gs_map_prepare(v, None, nv.ptr(g), w, h, cfg, 0, nv.ptr(tile_ranges), nv.ptr(counts), None,
                                 nv.ptr(scratch), nbytes, nv.stream()), "gs_map_prepare")
     k, max_tile = (int(x) for x in counts[:2].tolist())  # host sync (reference: full_cumsum.cu:45)
     overlap_to_point = torch.empty((k,), dtype=torch.int32, device=dev)
