@@ -228,6 +228,15 @@ int gs_depth_split_bwd(int64_t pixels, int32_t channels, const float* depth, con
                        const float* grad_features, const float* grad_depth, const float* grad_depth_var,
                        float* grad_image, void* stream);
 
+/* ------------------------------------------------------------------- Morton ordering --
+ * replaces: misc/morton_sort.py:78-88 code_points64_kernel (Grid.morton_code64, :37-66).  points (n,3);
+ * lower_host: 3 floats on the HOST (the grid origin, a min-reduction the caller already has);
+ * cell = clamp((p - lower)/inc, 0, size-1), size <= 2^21; codes (n) uint64.  Sorting the codes with
+ * gs_radix_sort_pairs gives misc/morton_sort.py:121-126 argsort.
+ */
+int gs_morton_codes64(int64_t n, const float* points, const float* lower_host, float inc, int32_t size,
+                      uint64_t* codes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,3 +66,42 @@ extern "C" int gs_depth_split_bwd(int64_t pixels, int32_t channels, const float*
   GS_CHECK_LAUNCH("gs_depth_split_bwd");
   return GS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// 3D Morton codes (reference misc/morton_sort.py:10-88): cell = clamp((p - lower) / inc, 0, size-1)
+// per axis, 21 bits per axis interleaved x | y<<1 | z<<2 into 63 bits.  Integer result: the f32
+// subtraction and division are single correctly rounded ops, so the codes are bit-exact.
+namespace {
+__device__ __forceinline__ uint64_t spread_bits64(uint64_t x) {
+  x &= 0x1fffffull;
+  x = (x | (x << 32)) & 0x1f00000000ffffull;
+  x = (x | (x << 16)) & 0x1f0000ff0000ffull;
+  x = (x | (x << 8)) & 0x100f00f00f00f00full;
+  x = (x | (x << 4)) & 0x10c30c30c30c30c3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ __launch_bounds__(256) void morton_kernel(int64_t n, const float* points, float lx, float ly, float lz,
+                                                     float inc, int size, uint64_t* codes) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float hi = float(size - 1);
+  const float vx = __fdiv_rn(points[3 * i] - lx, inc), vy = __fdiv_rn(points[3 * i + 1] - ly, inc),
+              vz = __fdiv_rn(points[3 * i + 2] - lz, inc);
+  const uint32_t cx = uint32_t(fminf(fmaxf(vx, 0.0f), hi)), cy = uint32_t(fminf(fmaxf(vy, 0.0f), hi)),
+                 cz = uint32_t(fminf(fmaxf(vz, 0.0f), hi));
+  codes[i] = spread_bits64(cx) | (spread_bits64(cy) << 1) | (spread_bits64(cz) << 2);
+}
+}  // namespace
+
+extern "C" int gs_morton_codes64(int64_t n, const float* points, const float* lower_host, float inc, int32_t size,
+                                 uint64_t* codes, void* stream) {
+  GS_REQUIRE(size > 0 && size <= (1 << 21) && inc > 0.0f, GS_ERR_INVALID_ARGUMENT, "gs_morton_codes64: grid");
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(points && lower_host && codes, GS_ERR_INVALID_ARGUMENT, "gs_morton_codes64: NULL buffer");
+  hipLaunchKernelGGL(morton_kernel, dim3(unsigned(gs_div_up(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, points, lower_host[0], lower_host[1], lower_host[2], inc, size, codes);
+  GS_CHECK_LAUNCH("gs_morton_codes64");
+  return GS_OK;
+}

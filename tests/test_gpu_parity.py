@@ -592,3 +592,39 @@ def test_float64_and_cpu_inputs_are_rejected_not_emulated():
         gs.render_gaussians(g.to(DEV).to(dtype=torch.float64), cam.to(dtype=torch.float64), RasterConfig(), use_sh=True)
     with pytest.raises(RuntimeError, match="HIP device"):
         gs.render_gaussians(g, cam, RasterConfig(), use_sh=True)
+
+
+# ------------------------------------------------------------------------- Morton ordering
+def _morton_numpy(points, resolution, size=2 ** 20):
+    """numpy restatement of reference misc/morton_sort.py:10-66, 91-99 (f32 cell arithmetic)"""
+    p = points.astype(np.float32)
+    lower = p.min(0)
+    upper = (lower + np.float32(size * resolution)).astype(np.float32)
+    inc = ((upper - lower) / np.float32(size)).astype(np.float32)[0]
+    v = ((p - lower) / inc).astype(np.float32)
+    cell = np.clip(v, 0, size - 1).astype(np.uint64)
+
+    def spread(x):
+        x = x & np.uint64(0x1fffff)
+        x = (x | (x << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        x = (x | (x << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        x = (x | (x << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        x = (x | (x << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        x = (x | (x << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return x
+    return spread(cell[:, 0]) | (spread(cell[:, 1]) << np.uint64(1)) | (spread(cell[:, 2]) << np.uint64(2))
+
+
+def test_morton_sort_bit_exact():
+    from taichi_gaussian_rasterizer_amd.misc import morton_sort
+    rng = np.random.default_rng(0)
+    for n, res in ((1, 0.01), (1000, 0.001), (200000, 0.0005)):
+        pts = (rng.standard_normal((n, 3)) * 3).astype(np.float32)
+        codes = pu.to_np(morton_sort.morton_codes(dev(pts), res)).view(np.uint64)
+        ref = _morton_numpy(pts, res)
+        assert (codes == ref).all()
+        order = pu.to_np(morton_sort.argsort(dev(pts), res))
+        assert (order == np.argsort(ref, kind="stable")).all()
+        assert torch.equal(morton_sort.sort(dev(pts), res), dev(pts[np.argsort(ref, kind="stable")]))
+    d = morton_sort.argsort_dedup(dev(np.zeros((10, 3), np.float32)), 0.1)
+    assert d.shape == (1,)
