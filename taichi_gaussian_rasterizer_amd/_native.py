@@ -73,6 +73,7 @@ class KernelTimer:
 
     def __init__(self):
         self.enabled = False
+        self.only = None   # optional set of entry-point names to time (None = all)
         self.records = {}  # name -> list of (start_event, end_event)
 
     def reset(self):
@@ -99,7 +100,7 @@ class _TimedLib:
             return fn
 
         def call(*args):
-            if not timer.enabled:
+            if not timer.enabled or (timer.only is not None and name not in timer.only):
                 return fn(*args)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
