@@ -29,8 +29,10 @@ _PINNED = {}  # device index -> ring of pinned int32[8] host buffers for the asy
 
 
 def _pinned_counts(dev: torch.device) -> torch.Tensor:
-    ring = _PINNED.setdefault(dev.index, dict(bufs=[torch.empty((8,), dtype=torch.int32).pin_memory()
-                                                    for _ in range(4)], at=0))
+    ring = _PINNED.get(dev.index)
+    if ring is None:
+        ring = _PINNED[dev.index] = dict(bufs=[torch.empty((8,), dtype=torch.int32).pin_memory() for _ in range(4)],
+                                         at=0)
     ring["at"] = (ring["at"] + 1) % len(ring["bufs"])
     return ring["bufs"][ring["at"]]
 
