@@ -115,6 +115,67 @@ __device__ __forceinline__ float gs_wave_reduce16_transposed(float (&v)[16], int
   return d;
 }
 
+// The same butterfly sized for exactly N <= 16 values (no work on padding): 25 instructions for N = 9.
+// After the call, lane l holds the wave total of value gs_reduce_slot<N>(l) (or garbage when that is -1).
+template <int N>
+struct GsReduceShape {
+  static constexpr int h1 = (N + 1) / 2, h2 = (h1 + 1) / 2, h3 = (h2 + 1) / 2, h4 = (h3 + 1) / 2;
+  static_assert(N >= 1 && N <= 16 && h4 == 1, "one register must remain after four halvings");
+};
+
+template <int N>
+__device__ __forceinline__ int gs_reduce_slot(int lane) {
+  typedef GsReduceShape<N> S;
+  const int row = lane >> 4, col = lane & 15;
+  const int ci = (col >> 2) & 1;                 // stage D picked c[ci]
+  if (ci >= S::h3) return -1;
+  const int bi = ci + ((col >> 3) & 1) * S::h3;  // stage C picked b[bi]
+  if (bi >= S::h2) return -1;
+  const int ai = bi + (row & 1) * S::h2;         // stage B: odd rows carry a[bi + h2]
+  if (ai >= S::h1) return -1;
+  const int vi = ai + (row >> 1) * S::h1;        // stage A: upper half carries v[ai + h1]
+  return vi < N ? vi : -1;
+}
+
+template <int N>
+__device__ __forceinline__ float gs_wave_reduce_transposed(float (&v)[N], int lane) {
+  typedef GsReduceShape<N> S;
+  float a[S::h1];
+#pragma unroll
+  for (int i = 0; i < S::h1; ++i) {
+    const float partner = (i + S::h1 < N) ? v[i + S::h1 < N ? i + S::h1 : 0] : 0.0f;
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(partner), false, false);
+    a[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  float b[S::h2];
+#pragma unroll
+  for (int i = 0; i < S::h2; ++i) {
+    const float partner = (i + S::h2 < S::h1) ? a[i + S::h2 < S::h1 ? i + S::h2 : 0] : 0.0f;
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a[i]), __float_as_uint(partner), false, false);
+    b[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const bool hi8 = (lane & 8) != 0, hi4 = (lane & 4) != 0;
+  float c[S::h3];
+#pragma unroll
+  for (int i = 0; i < S::h3; ++i) {
+    const float t = gs_dpp_add_full<0x128>(b[i]);  // row_ror:8
+    if (i + S::h3 < S::h2) {
+      const float u = gs_dpp_add_full<0x128>(b[i + S::h3 < S::h2 ? i + S::h3 : 0]);
+      c[i] = hi8 ? u : t;
+    } else {
+      c[i] = t;
+    }
+  }
+  float d = gs_dpp_add_full<0x141>(c[0]);            // row_half_mirror
+  if (S::h3 > 1) {
+    const float u = gs_dpp_add_full<0x141>(c[S::h3 > 1 ? 1 : 0]);
+    d = hi4 ? u : d;
+  }
+  d = gs_dpp_add_full<0xB1>(d);  // quad_perm:[1,0,3,2]
+  d = gs_dpp_add_full<0x4E>(d);  // quad_perm:[2,3,0,1]
+  return d;
+}
+
 __device__ __forceinline__ float gs_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float gs_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
 

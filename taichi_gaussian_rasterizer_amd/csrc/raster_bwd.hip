@@ -96,6 +96,8 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + GEO_F + FEAT_F);
   float(*s_out)[OUT_STRIDE] = reinterpret_cast<float(*)[OUT_STRIDE]>(smem);
 
+  // which value of the per-splat reduction this lane ends up owning (lane-constant; -1 = none)
+  const int my_slot = (NACC <= 16 && (lane & 3) == 0) ? gs_reduce_slot<(NACC <= 16 ? NACC : 1)>(lane) : -1;
   const int lx = lane & 7, ly = lane >> 3;
   float Xf[NB], Yf[NB], Wt[NB], R[NB], gpix[NB][FP];
 #pragma unroll
@@ -262,19 +264,27 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
 
       // reduce over the wave only if some pixel took a gradient (backward.py:204)
       if (__ballot(has_grad) != 0ull) {
-        // transposed butterfly: 16 values at a time, lane l ends up with the total of value l>>2,
-        // and one ds_write_b32 (16 active lanes) stores them
+        // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
+        // up owning value k stores it (one ds_write_b32 for all values of a chunk)
+        if (NACC <= 16) {
+          float vals[NACC <= 16 ? NACC : 1];
 #pragma unroll
-        for (int base = 0; base < NACC; base += 16) {
-          float vals[16];
+          for (int c = 0; c < NACC && c < 16; ++c) vals[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];
+          const float tot = gs_wave_reduce_transposed<(NACC <= 16 ? NACC : 1)>(vals, lane);
+          if (my_slot >= 0) s_acc[j][my_slot] = tot;
+        } else {
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            const int k = base + c;
-            vals[c] = k < NS ? S[k < NS ? k : 0] : (k < NACC ? gf[(k - NS) < FP && k >= NS ? (k - NS) : 0] : 0.0f);
+          for (int base = 0; base < NACC; base += 16) {
+            float vals[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              const int k = base + c;
+              vals[c] = k < NS ? S[k < NS ? k : 0] : (k < NACC ? gf[(k - NS) < FP && k >= NS ? (k - NS) : 0] : 0.0f);
+            }
+            const float tot = gs_wave_reduce16_transposed(vals, lane);
+            const int k = base + (lane >> 2);
+            if ((lane & 3) == 0 && k < NACC) s_acc[j][k] = tot;
           }
-          const float tot = gs_wave_reduce16_transposed(vals, lane);
-          const int k = base + (lane >> 2);
-          if ((lane & 3) == 0 && k < NACC) s_acc[j][k] = tot;
         }
       }
     }
