@@ -174,7 +174,6 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
     for (int j = 0; j < cnt; ++j) {
       const float4 g0v = s_geo[j][0], g1v = s_geo[j][1];
       const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
-      if (mask == 0) continue;
       float4 g2v = make_float4(0, 0, 0, 0);
       if (FULL) g2v = s_geo[j][2];
       float feat[FP];

@@ -157,7 +157,6 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
         for (int c = 0; c < FP; ++c) nfeat[c] = s_feat[jn][c];
       }
       const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
-      if (mask == 0) continue;
       float vis_sum = 0.0f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
