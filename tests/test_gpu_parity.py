@@ -628,3 +628,40 @@ def test_morton_sort_bit_exact():
         assert torch.equal(morton_sort.sort(dev(pts), res), dev(pts[np.argsort(ref, kind="stable")]))
     d = morton_sort.argsort_dedup(dev(np.zeros((10, 3), np.float32)), 0.1)
     assert d.shape == (1,)
+
+
+# ---------------------------------------------------------- skewed splat-size distribution
+def test_mapper_and_raster_with_huge_and_tiny_splats():
+    """real scenes mix sub-pixel splats with a few that cover most of the screen: exercises the
+    mapper's outside-window path (splats reaching beyond their region's LDS window), long per-lane
+    tile loops, crowded tiles (bitonic sort) and deep blend lists; results must still match the oracle
+    bit for bit (mapper) / within tolerance (rasterizer)."""
+    size, n = (640, 400), 6000
+    rng = np.random.default_rng(7)
+    mean = rng.random((n, 2)) * np.array(size)
+    ang = rng.random(n) * 2 * np.pi
+    axis = np.stack([np.cos(ang), np.sin(ang)], 1)
+    sig = np.exp(rng.normal(1.0, 1.2, (n, 2)))                 # log-normal: 0.1 .. 100 px
+    big = rng.choice(n, 60, replace=False)
+    sig[big] = rng.uniform(80, 400, (60, 2))                   # 1 % cover large parts of the image
+    alpha = rng.uniform(0.05, 0.9, (n, 1))
+    g2d = np.concatenate([mean, axis, sig, alpha], 1).astype(np.float32)
+    depth = rng.random((n, 1)).astype(np.float32)
+    feat = rng.random((n, 3)).astype(np.float32)
+    cfg = RasterConfig()
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p_ref, ranges_ref = orc.map_to_tiles(g2d, depth, size, ocfg)
+    o2p, ranges = gs.map_to_tiles(dev(g2d), dev(depth), size, cfg)
+    assert (pu.to_np(ranges) == ranges_ref).all() and (pu.to_np(o2p) == o2p_ref).all()
+    counts = (ranges_ref[..., 1] - ranges_ref[..., 0])
+    assert counts.max() > 64 and o2p_ref.shape[0] > 5 * n       # deep lists, many overlaps per splat
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p_ref, ranges_ref, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, o2p, ranges.view(-1, 2), size, cfg)
+    pu.assert_pixels_close(out.image, image_ref, "image")
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    gi = torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(2))
+    (out.image * dev(gi)).sum().backward()
+    gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p_ref, ranges_ref, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d", tol=5e-4)
+    pu.assert_grad_close(f_t.grad, gf, "grad_features", tol=5e-4)
