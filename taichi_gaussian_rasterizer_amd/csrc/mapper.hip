@@ -211,9 +211,22 @@ __global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i < live_count(a)) {
-    const int r = region_of_gaussian(a.points + 7 * i, a, rg);
+    // Gaussians that touch no tile at all (off-screen within the cull margin; above or below this
+    // rank's strip when the frame is sharded) are left out of the ordering, so the counting and
+    // bucketing passes never see them.  The decision is the query itself -- same tests, same result.
+    const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
+    bool any = false;
+    if (q.span_x > 0 && q.span_y > 0) {
+      if (q.span_x * q.span_y > 16) {
+        any = true;  // large candidate set: let the counting pass decide
+      } else {
+        for (int ty = 0; ty < q.span_y && !any; ++ty)
+          for (int tx = 0; tx < q.span_x && !any; ++tx) any = test_tile(q, tx, ty, a.tile_size);
+      }
+    }
+    const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
-    atomicAdd(&s_hist[r], 1);
+    if (r >= 0) atomicAdd(&s_hist[r], 1);
   }
   __syncthreads();
   for (int r = threadIdx.x; r < rg.num_regions; r += 256) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
@@ -273,8 +286,10 @@ __global__ __launch_bounds__(256) void region_scatter_kernel(MapArgs a, RegionGr
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (i < live_count(a)) {
     const int r = region_of[i];
-    const int local = atomicAdd(&s_cnt[r], 1);
-    order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = int(i);
+    if (r >= 0) {
+      const int local = atomicAdd(&s_cnt[r], 1);
+      order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = int(i);
+    }
   }
 }
 
