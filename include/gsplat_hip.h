@@ -237,6 +237,17 @@ int gs_depth_split_bwd(int64_t pixels, int32_t channels, const float* depth, con
 int gs_morton_codes64(int64_t n, const float* points, const float* lower_host, float inc, int32_t size,
                       uint64_t* codes, void* stream);
 
+/* ------------------------------------------------ sparse / fractional optimizer step (8f-3) --
+ * replaces: optim/fractional_adam.py:7-85 and optim/fractional_laprop.py scalar_kernel / vector_kernel.
+ * For each visible row i (idx = indexes[i], int64) with fractional weight weight[i]: update the running
+ * moments m, v of row idx in place and write lr_step (rows, dims).  laprop: 0 = Adam, 1 = LaProp;
+ * vector_group: 0 = per-element second moment v (N,dims), 1 = one v per row (N) from |g|^2.
+ * m (N,dims), total_weight (N), grad (N,dims).
+ */
+int gs_optim_step(int32_t laprop, int32_t vector_group, int64_t rows, int32_t dims, const int64_t* indexes,
+                  const float* weight, float* m, float* v, const float* total_weight, const float* grad, float lr,
+                  float beta1, float beta2, float eps, int32_t bias_correction, float* lr_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
