@@ -38,6 +38,7 @@ WORKLOADS = {
     "c4": dict(n=1_000_000, size=(2048, 2048), sh_degree=3, backward=True, depth=True),
     "c5": dict(n=6_000_000, size=(4096, 4096), sh_degree=3, backward=True, depth=False),
 }
+VALU_ISSUE_NS, NUM_SIMDS = 1.1, 1024  # tools/ubench/valu_rate.hip; 256 CUs x 4 SIMDs
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 
 
@@ -201,6 +202,13 @@ def main():
                     rec = json.load(open(pmc)).get(args.workload, {}).get(dom)
                     if rec and world == 1:
                         roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                        if "valu_wave_insts_per_launch" in rec:
+                            # the kernel is f32-VALU-issue-bound (no MFMA shape, HBM far from saturated): second
+                            # roofline = measured wave64 VALU instructions against the chip's issue rate
+                            insts = rec["valu_wave_insts_per_launch"]
+                            floor_ms = insts * VALU_ISSUE_NS / NUM_SIMDS * 1e-6
+                            roofline["valu"] = dict(wave_insts_per_launch=insts, issue_floor_ms=round(floor_ms, 4),
+                                                    issue_frac=round(floor_ms / stages[dom]["avg_launch_ms"], 4))
                 except Exception:
                     pass
     whole = sum(v for k, v in by.items() if wl["backward"] or not k.endswith(("_bwd", "_unpack")))
