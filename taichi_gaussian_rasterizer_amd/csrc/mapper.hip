@@ -110,68 +110,82 @@ __device__ __forceinline__ int64_t live_count(const MapArgs& a) {
 }
 
 // ---- fused path -------------------------------------------------------------------------
-// single-workgroup exclusive scan over the T-entry histogram (T <= 65536 + slack)
-__global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
-                                                        int* cursors, int* counts_out, int64_t k_capacity) {
-  __shared__ int s_part[1024];
-  __shared__ int s_max[1024];
-  const int t = threadIdx.x;
-  const int per = (num_tiles + 1023) / 1024;
-  const int lo = t * per, hi = min(lo + per, num_tiles);
-  int sum = 0, mx = 0;
-  for (int i = lo; i < hi; ++i) { const int c = tile_hist[i]; sum += c; mx = max(mx, c); }
-  s_part[t] = sum;
-  s_max[t] = mx;
-  __syncthreads();
-  // Hillis-Steele inclusive scan of the 1024 partials
-  for (int off = 1; off < 1024; off <<= 1) {
-    int vsum = s_part[t], vmax = s_max[t];
-    if (t >= off) { vsum += s_part[t - off]; vmax = max(vmax, s_max[t - off]); }
-    __syncthreads();
-    s_part[t] = vsum; s_max[t] = vmax;
-    __syncthreads();
-  }
-  int run = s_part[t] - sum;  // exclusive prefix of this thread's chunk
-  for (int i = lo; i < hi; ++i) {
-    const int c = tile_hist[i];
-    // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
-    // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
-    const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
-    tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
-    cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
-    run += c;
-  }
-  if (t == 1023) {
-    counts_out[0] = s_part[1023];
-    counts_out[1] = s_max[1023];
-    counts_out[2] = (k_capacity > 0 && int64_t(s_part[1023]) > k_capacity) ? 1 : 0;
-    counts_out[3] = 0;
-  }
+// inclusive scan over the wave: row_shr 1/2/4/8 inside each 16-lane row, then row_bcast:15 / :31 across rows
+__device__ __forceinline__ int wave_inclusive_scan(int x) {
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+  return x;
 }
 
-// Launch order for the rasterizer: tiles by descending population (counting sort on min(count, 1023)).
-// The order inside a bin comes from LDS atomics and is arbitrary; it only affects scheduling.
-__global__ __launch_bounds__(1024) void tile_order_kernel(int num_tiles, const int* tile_hist, int* tile_order) {
+// exclusive prefix of x over the 1024 threads of the workgroup (s_wave: 16 ints of LDS); total -> sum
+__device__ __forceinline__ int block_exclusive_scan(int x, int* s_wave, int& sum) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int inc = wave_inclusive_scan(x);
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  int before = 0;
+  sum = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int tot = s_wave[w];
+    sum += tot;
+    before += w < wv ? tot : 0;
+  }
+  __syncthreads();  // s_wave is reused by the caller's next round
+  return before + inc - x;
+}
+
+// Single workgroup: exclusive scan of the T-entry tile histogram (coalesced rounds of 1024 tiles) ->
+// tile_ranges, bucket cursors, K, fullest tile, overflow flag; and, in the same pass, the rasterizer's
+// launch order: tiles by descending population (counting sort on min(count, 1023); the order inside a
+// bin comes from LDS atomics and is arbitrary -- it only affects scheduling).
+__global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
+                                                        int* cursors, int* counts_out, int64_t k_capacity,
+                                                        int* tile_order) {
+  __shared__ int s_wave[16];
   __shared__ int s_bin[1024];
-  __shared__ int s_scan[1024];
   const int t = threadIdx.x;
   s_bin[t] = 0;
   __syncthreads();
-  for (int i = t; i < num_tiles; i += 1024) atomicAdd(&s_bin[min(tile_hist[i], 1023)], 1);
-  __syncthreads();
-  // start of bin b in descending order = number of tiles in bins above b: suffix scan
-  s_scan[t] = s_bin[1023 - t];
-  __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {
-    int x = s_scan[t];
-    if (t >= off) x += s_scan[t - off];
-    __syncthreads();
-    s_scan[t] = x;
-    __syncthreads();
+  int carry = 0, mx = 0;
+  for (int base = 0; base < num_tiles; base += 1024) {
+    const int i = base + t;
+    const int c = i < num_tiles ? tile_hist[i] : 0;
+    mx = max(mx, c);
+    if (tile_order && i < num_tiles) atomicAdd(&s_bin[min(c, 1023)], 1);
+    int total;
+    const int run = carry + block_exclusive_scan(c, s_wave, total);
+    carry += total;
+    if (i < num_tiles) {
+      // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
+      // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
+      const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
+      tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
+      cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
+    }
   }
-  const int start = s_scan[t] - s_bin[1023 - t];  // exclusive, for bin 1023 - t
+  // fullest tile
+  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+  if ((t & 63) == 0) s_wave[t >> 6] = mx;
   __syncthreads();
-  s_bin[1023 - t] = start;
+  if (t == 0) {
+    int m = 0;
+    for (int w = 0; w < 16; ++w) m = max(m, s_wave[w]);
+    counts_out[0] = carry;
+    counts_out[1] = m;
+    counts_out[2] = (k_capacity > 0 && int64_t(carry) > k_capacity) ? 1 : 0;
+    counts_out[3] = 0;
+  }
+  if (!tile_order) return;
+  __syncthreads();
+  // start of bin b in descending order = number of tiles in fuller bins: scan the bins from the top
+  int unused;
+  const int start = block_exclusive_scan(s_bin[1023 - t], s_wave, unused);
+  s_bin[1023 - t] = start;  // read above and written here by the same thread only
   __syncthreads();
   for (int i = t; i < num_tiles; i += 1024) tile_order[atomicAdd(&s_bin[min(tile_hist[i], 1023)], 1)] = i;
 }
@@ -759,8 +773,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
   hipLaunchKernelGGL(map_scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist,
-                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity);
-  if (tile_order) hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist, tile_order);
+                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity, tile_order);
   GS_CHECK_LAUNCH("gs_map_prepare/scan");
   return GS_OK;
 }
