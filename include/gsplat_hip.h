@@ -72,6 +72,7 @@ int gs_version(void);
  *   [z, z^2] in its first two columns (renderer.py:191-193, render_depth=True).
  *   mean_y_offset is subtracted from the projected mean.y as it is written (0 for a whole image; the
  *   origin row of a tile-row strip when the frame is sharded over GPUs -- culling still uses the full image).
+ *   camera_pos (optional, 3 floats): receives the camera centre, as gs_camera_position would (saves its launch).
  * scratch: gs_project_scratch_bytes(n).
  */
 int64_t gs_project_scratch_bytes(int64_t n);
@@ -79,8 +80,8 @@ int gs_project_fwd(int64_t n, const float* position, const float* log_scaling, c
                    const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
                    int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
                    float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
-                   float* depth_features, int32_t depth_features_stride, float mean_y_offset, void* scratch,
-                   int64_t scratch_bytes, void* stream);
+                   float* depth_features, int32_t depth_features_stride, float mean_y_offset, float* camera_pos,
+                   void* scratch, int64_t scratch_bytes, void* stream);
 
 /* replaces: perspective/projection.py:84-118 indexed_project_kernel.grad (Taichi autodiff,
  * :166-185).  Hand-derived adjoint.  Dense gradients (rows of culled Gaussians are zero);

@@ -36,7 +36,7 @@ SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_project_scratch_bytes": (_I64, [_I64]),
     "gs_project_fwd": (ctypes.c_int, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _F64, _F64, _CFG, _P, _P, _P, _P, _P,
-                                       _P, _P, _I32, c_float, _P, _I64, _P]),
+                                       _P, _P, _I32, c_float, _P, _P, _I64, _P]),
     "gs_project_bwd_scratch_bytes": (_I64, [_I64]),
     "gs_project_bwd": (ctypes.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _CFG, _P, _P, _I32, _P, _P,
                                        _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),

@@ -109,10 +109,28 @@ __device__ __forceinline__ void forward(const ProjArgs& a, const Cam& c, int64_t
   f.alpha = 1.0f / (1.0f + expf(-a.alpha_logit[i]));
 }
 
+// camera position = -R^-1 t of the (affine) camera matrix, on the device: CameraParams.camera_position
+// (params.py:76-78) without the host round trip of a 4x4 torch.inverse
+__device__ __forceinline__ void camera_position(const float* T, float* out) {
+  const float a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
+  const float tx = T[3], ty = T[7], tz = T[11];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  const float inv = 1.0f / det;
+  // inverse(R) rows
+  const float r00 = A * inv, r01 = -(b * i - c * h) * inv, r02 = (b * f - c * e) * inv;
+  const float r10 = B * inv, r11 = (a * i - c * g) * inv, r12 = -(a * f - c * d) * inv;
+  const float r20 = C * inv, r21 = -(a * h - b * g) * inv, r22 = (a * e - b * d) * inv;
+  out[0] = -(r00 * tx + r01 * ty + r02 * tz);
+  out[1] = -(r10 * tx + r11 * ty + r12 * tz);
+  out[2] = -(r20 * tx + r21 * ty + r22 * tz);
+}
+
 // pass 1: project everything, stage rows, count visible per block
-__global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_rows, int* block_counts) {
+__global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_rows, int* block_counts, float* cam_out) {
   __shared__ int s_cnt[4];
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (cam_out && blockIdx.x == 0 && threadIdx.x == 0) camera_position(a.T44, cam_out);
   bool vis = false;
   if (i < a.n) {
     const Cam c = load_cam(a.T44, a.proj);
@@ -136,12 +154,15 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_row
 }
 
 // pass 2: stable compaction
+// block_offsets == nullptr: every workgroup sums the visible counts of the workgroups before it itself
+// (block_counts, a few KB that stay in L2) instead of reading a prefix computed by three scan launches
 __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* st_rows, const int* block_offsets,
-                                                      int num_blocks, float inv_far, float ndc_denom, float* points,
+                                                      const int* block_counts, int num_blocks, float inv_far, float ndc_denom, float* points,
                                                       float* depth, float* ndc, int64_t* indexes, int* slot_of,
                                                       int* num_visible, float* depth_feat, int depth_feat_stride,
                                                       float mean_y_offset) {
   __shared__ int s_cnt[4];
+  __shared__ int s_before[4];
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
   bool vis = false;
@@ -153,8 +174,15 @@ __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* s
   const uint64_t b = __ballot(vis);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) s_cnt[wave] = __popcll(b);
+  int before = 0;
+  if (!block_offsets) {
+    for (int j = threadIdx.x; j < int(blockIdx.x); j += 256) before += block_counts[j];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if (lane == 0) s_before[wave] = before;
+  }
   __syncthreads();
-  int base = block_offsets[blockIdx.x];
+  int base = block_offsets ? block_offsets[blockIdx.x] : s_before[0] + s_before[1] + s_before[2] + s_before[3];
+  const int block_start = base;
   for (int w = 0; w < wave; ++w) base += s_cnt[w];
   if (i < n) {
     int slot = -1;
@@ -175,7 +203,8 @@ __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* s
     }
     slot_of[i] = slot;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *num_visible = block_offsets[num_blocks];
+  if (int(blockIdx.x) == num_blocks - 1 && threadIdx.x == 0)
+    *num_visible = block_start + s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // ------------------------------------------------------------------------------- backward
@@ -351,22 +380,8 @@ __global__ __launch_bounds__(256) void cam_reduce_kernel(int num_blocks, const f
   if (threadIdx.x < 4 && dT44) dT44[12 + threadIdx.x] = 0.0f;
 }
 
-// camera position = -R^-1 t of the (affine) camera matrix, on the device: CameraParams.camera_position
-// (params.py:76-78) without the host round trip of a 4x4 torch.inverse
 __global__ void camera_position_kernel(const float* T, float* out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const float a = T[0], b = T[1], c = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
-  const float tx = T[3], ty = T[7], tz = T[11];
-  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
-  const float det = a * A + b * B + c * C;
-  const float inv = 1.0f / det;
-  // inverse(R) rows
-  const float r00 = A * inv, r01 = -(b * i - c * h) * inv, r02 = (b * f - c * e) * inv;
-  const float r10 = B * inv, r11 = (a * i - c * g) * inv, r12 = -(a * f - c * d) * inv;
-  const float r20 = C * inv, r21 = -(a * h - b * g) * inv, r22 = (a * e - b * d) * inv;
-  out[0] = -(r00 * tx + r01 * ty + r02 * tz);
-  out[1] = -(r10 * tx + r11 * ty + r12 * tz);
-  out[2] = -(r20 * tx + r21 * ty + r22 * tz);
+  if (threadIdx.x == 0 && blockIdx.x == 0) camera_position(T, out);
 }
 
 int fill(ProjArgs& a, int64_t n, const float* position, const float* log_scaling, const float* rotation,
@@ -400,7 +415,7 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
                               int32_t width, int32_t height, double near_plane, double far_plane,
                               const GsRasterConfig* cfg, float* points, float* depth, float* ndc_depth,
                               int64_t* indexes, int32_t* slot_of, int32_t* num_visible, float* depth_features,
-                              int32_t depth_features_stride, float mean_y_offset, void* scratch,
+                              int32_t depth_features_stride, float mean_y_offset, float* camera_pos, void* scratch,
                               int64_t scratch_bytes, void* stream) {
   ProjArgs a;
   if (int rc = fill(a, n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
@@ -411,6 +426,7 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (n == 0) {
     if (hipMemsetAsync(num_visible, 0, 4, s) != hipSuccess) { gs_set_error("gs_project_fwd: memset failed"); return GS_ERR_LAUNCH; }
+    if (camera_pos) return gs_camera_position(T_camera_world, camera_pos, stream);
     return GS_OK;
   }
   GS_REQUIRE(points && depth && ndc_depth && indexes && slot_of && scratch, GS_ERR_INVALID_ARGUMENT,
@@ -423,10 +439,14 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
   int* counts = reinterpret_cast<int*>(base + gs_align_up(n * 32, 256));
   int* offsets = counts + gs_align_up(int64_t(nb + 1) * 4, 256) / 4;
   void* scan_scratch = offsets + gs_align_up(int64_t(nb + 1) * 4, 256) / 4;
-  hipLaunchKernelGGL(project_kernel, dim3(nb), dim3(256), 0, s, a, st_rows, counts);
+  hipLaunchKernelGGL(project_kernel, dim3(nb), dim3(256), 0, s, a, st_rows, counts, camera_pos);
   GS_CHECK_LAUNCH("gs_project_fwd/project");
-  if (int rc = gs_full_cumsum_i32(nb, counts, offsets, scan_scratch, gs_cumsum_scratch_bytes(nb), s)) return rc;
-  hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, s, n, st_rows, offsets, nb, a.inv_far, a.ndc_denom,
+  // up to 16384 workgroups (4M Gaussians) each workgroup adds up the counts in front of it (<= 64 KB out of
+  // L2); beyond that the quadratic read volume loses to a proper scan
+  const bool self_offsets = nb <= 16384;
+  if (!self_offsets)
+    if (int rc = gs_full_cumsum_i32(nb, counts, offsets, scan_scratch, gs_cumsum_scratch_bytes(nb), s)) return rc;
+  hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, s, n, st_rows, self_offsets ? nullptr : offsets, counts, nb, a.inv_far, a.ndc_denom,
                      points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride,
                      mean_y_offset);
   GS_CHECK_LAUNCH("gs_project_fwd/compact");

@@ -83,8 +83,7 @@ class _FusedRender(torch.autograd.Function):
                                     nv.ptr(T), nv.ptr(proj), w, full_h, float(depth_range[0]), float(depth_range[1]),
                                     cfg, nv.ptr(points), nv.ptr(depth), nv.ptr(ndc), nv.ptr(indexes),
                                     nv.ptr(slot_of), nv.ptr(counts), nv.ptr(feats) if render_depth else None, F,
-                                    float(y0), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
-        nv.check(lib.gs_camera_position(nv.ptr(T), nv.ptr(cam_pos), s), "gs_camera_position")
+                                    float(y0), nv.ptr(cam_pos), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
         v_dev = nv.ptr(counts)
         nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
                                nv.ptr(cam_pos), _off(feats, col0), F, s), "gs_sh_fwd")

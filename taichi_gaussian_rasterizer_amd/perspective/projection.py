@@ -48,7 +48,7 @@ class _ProjectFunction(torch.autograd.Function):
                                     nv.ptr(T), nv.ptr(proj), int(image_size[0]), int(image_size[1]),
                                     float(depth_range[0]), float(depth_range[1]), cfg, nv.ptr(points), nv.ptr(depth),
                                     nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of), nv.ptr(count), None, 0, 0.0,
-                                    nv.ptr(scratch), nbytes, nv.stream()), "gs_project_fwd")
+                                    None, nv.ptr(scratch), nbytes, nv.stream()), "gs_project_fwd")
         v = int(count.item())  # the one host sync of the stage (the reference's torch.nonzero, :146)
         points, depth, ndc, indexes = points[:v], depth[:v], ndc[:v], indexes[:v]
         ctx.image_size = (int(image_size[0]), int(image_size[1]))
