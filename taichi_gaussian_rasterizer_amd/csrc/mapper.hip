@@ -498,29 +498,51 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const
 
 // Rank sort, one WAVE per tile, for buckets of up to 64*R pairs (the common case: a few hundred
 // splats per tile).  Keys are unique (the Gaussian index is the low word), so the rank of a key
-// -- the number of keys below it -- is its final position: each lane keeps R keys in registers,
-// every key of the bucket is broadcast from LDS once (one wave-uniform ds_read_b64), and lanes
-// count.  n^2/64 compares per tile, no barriers, no data-dependent control flow; ~5x faster than
-// the LDS bitonic network at these sizes.
+// -- the number of keys below it -- is its final position.  Each lane keeps R keys in registers
+// (row q = keys q*64 .. q*64+63).  Two levels:
+//   1. every row is ranked against ITSELF: 64 wave-uniform LDS broadcasts per row, lanes count
+//      (n compares per lane instead of n*R), and the row is written back to LDS in sorted order;
+//   2. a key's rank among the other rows is a lower bound in each of those sorted rows: 7 probes.
+// No barriers (a workgroup is one wave), no data-dependent control flow.  Slots past n hold pad keys
+// 0xFFFFFFFF'00000000 | slot: unique, above every real key (the high word of a real key is the bit
+// pattern of a depth in [0,1] or a 16-bit code), so they sort to the end of their row.
 template <int R>
-__device__ __forceinline__ void rank_sort_rows(const uint64_t* s_key, const uint64_t* seg, int n, int lane, int start,
-                                               int tile, int* o2p, uint64_t* keys_out, int shift) {
+__device__ __forceinline__ void rank_sort_rows(uint64_t* s_key, int n, int lane, int start, int tile, int* o2p,
+                                               uint64_t* keys_out, int shift) {
   uint64_t mine[R];
   int rank[R];
 #pragma unroll
   for (int q = 0; q < R; ++q) {
-    const int i = q * 64 + lane;
-    mine[q] = i < n ? s_key[i] : ~0ull;
+    mine[q] = s_key[q * 64 + lane];
     rank[q] = 0;
   }
-  for (int j = 0; j < n; ++j) {
-    const uint64_t kj = s_key[j];
+  if (R == 1) {
+    for (int j = 0; j < n; ++j) rank[0] += s_key[j] < mine[0] ? 1 : 0;
+  } else {
+    for (int j = 0; j < 64; ++j) {
 #pragma unroll
-    for (int q = 0; q < R; ++q) rank[q] += kj < mine[q] ? 1 : 0;
+      for (int q = 0; q < R; ++q) rank[q] += s_key[q * 64 + j] < mine[q] ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < R; ++q) s_key[q * 64 + rank[q]] = mine[q];  // in place: every broadcast above is done
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+#pragma unroll
+      for (int p = 0; p < R; ++p) {
+        if (p == q) continue;
+        const uint64_t* row = s_key + p * 64;
+        int pos = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) pos += row[pos + step - 1] < mine[q] ? step : 0;
+        pos += row[pos] < mine[q] ? 1 : 0;
+        rank[q] += pos;
+      }
+    }
   }
 #pragma unroll
   for (int q = 0; q < R; ++q) {
-    if (q * 64 + lane < n) {
+    if ((mine[q] >> 32) != 0xFFFFFFFFull) {
       o2p[start + rank[q]] = int(uint32_t(mine[q]));
       if (keys_out) keys_out[start + rank[q]] = (mine[q] >> 32) | (uint64_t(uint32_t(tile)) << shift);
     }
@@ -556,13 +578,14 @@ __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const
     return;
   }
   const uint64_t* seg = pairs + r.x;
-  for (int i = lane; i < n; i += 64) s_key[i] = seg[i];
+  const int rows = n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 4 : n <= 512 ? 8 : 16;
+  for (int i = lane; i < rows * 64; i += 64) s_key[i] = i < n ? seg[i] : (0xFFFFFFFF00000000ull | uint64_t(i));
   __syncthreads();
-  if (n <= 64) rank_sort_rows<1>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (n <= 128) rank_sort_rows<2>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (n <= 256) rank_sort_rows<4>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (RMAX >= 8 && n <= 512) rank_sort_rows<(RMAX >= 8 ? 8 : 4)>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (RMAX >= 16) rank_sort_rows<(RMAX >= 16 ? 16 : 4)>(s_key, seg, n, lane, r.x, tile, o2p, keys_out, shift);
+  if (rows == 1) rank_sort_rows<1>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (rows == 2) rank_sort_rows<2>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (rows == 4) rank_sort_rows<4>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (RMAX >= 8 && rows == 8) rank_sort_rows<(RMAX >= 8 ? 8 : 4)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
+  else if (RMAX >= 16) rank_sort_rows<(RMAX >= 16 ? 16 : 4)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
 }
 
 // ---- reference-shaped primitives ----------------------------------------------------------

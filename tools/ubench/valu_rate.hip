@@ -58,6 +58,25 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float a, float b
         asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x4) : "v"(a)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x5) : "v"(a));
         asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x6) : "v"(a)); asm volatile("v_mul_f32 %0, %0, %1" : "+v"(x7) : "v"(a));
       }
+    } else if (MODE == 5 || MODE == 6) {  // compare + add-with-carry pairs: 64-bit (5) or 32-bit (6) compare
+      unsigned long k0 = threadIdx.x * 77u + i, k1 = k0 * 3u;
+      unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+      unsigned long m0 = threadIdx.x, m1 = m0 + 9, m2 = m0 + 17, m3 = m0 + 29;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (MODE == 5) {
+          asm volatile("v_cmp_lt_u64 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r0) : "v"(k0), "v"(m0) : "vcc");
+          asm volatile("v_cmp_lt_u64 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r1) : "v"(k0), "v"(m1) : "vcc");
+          asm volatile("v_cmp_lt_u64 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r2) : "v"(k1), "v"(m2) : "vcc");
+          asm volatile("v_cmp_lt_u64 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r3) : "v"(k1), "v"(m3) : "vcc");
+        } else {
+          asm volatile("v_cmp_lt_u32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r0) : "v"(unsigned(k0)), "v"(unsigned(m0)) : "vcc");
+          asm volatile("v_cmp_lt_u32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r1) : "v"(unsigned(k0)), "v"(unsigned(m1)) : "vcc");
+          asm volatile("v_cmp_lt_u32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r2) : "v"(unsigned(k1)), "v"(unsigned(m2)) : "vcc");
+          asm volatile("v_cmp_lt_u32 vcc, %1, %2\n v_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(r3) : "v"(unsigned(k1)), "v"(unsigned(m3)) : "vcc");
+        }
+      }
+      x0 += float(r0 + r1 + r2 + r3);
     }
   }
   out[blockIdx.x * blockDim.x + threadIdx.x] = x0 + x1 + x2 + x3 + x4 + x5 + x6 + x7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
@@ -91,6 +110,8 @@ int main() {
     run<2>("v_exp_f32", w, 64);
     run<3>("v_add_f32_dpp", w, 64);
     run<4>("v_mul_f32", w, 64);
+    run<5>("cmp_u64+addc", w, 64);
+    run<6>("cmp_u32+addc", w, 64);
   }
   return 0;
 }
