@@ -198,14 +198,17 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
 // workgroup), then lets every workgroup -- whose 256 Gaussians now share one region -- count its
 // overlaps in an LDS window covering the region plus a border, and touch global memory once per
 // window tile with row-contiguous (coalescing) atomics: ~12x fewer atomic requests.
-constexpr int RG = 32;                 // region edge in tiles
+// The region edge is the smallest power of two >= RG_MIN that keeps the region count <= MAX_REGIONS: the
+// smaller the region, the more of a workgroup's overlaps share a window tile, i.e. the fewer global atomics
+// (8x8-tile regions: ~5 overlaps per atomic at 256 Gaussians per workgroup; 32x32: ~1.4).
+constexpr int RG_MIN = 8;              // smallest region edge in tiles
 constexpr int RB = 4;                  // window border in tiles (splats reaching further fall back to global atomics)
-constexpr int WIN = RG + 2 * RB;       // window edge
-constexpr int WIN_TILES = WIN * WIN;   // 1600 ints = 6.4 KB of LDS
 constexpr int MAX_REGIONS = 1024;
 
 struct RegionGrid {
   int tiles_x, tiles_y, regions_x, num_regions;
+  int rg;    // region edge in tiles
+  int win;   // window edge = rg + 2 RB; the LDS window holds win * win ints
 };
 
 __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs& a, const RegionGrid& rg) {
@@ -213,7 +216,7 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
   int tx = int(floorf(g[0] / ts)), ty = int(floorf(g[1] / ts));
   tx = min(max(tx, 0), rg.tiles_x - 1);
   ty = min(max(ty, 0), rg.tiles_y - 1);
-  return (ty / RG) * rg.regions_x + (tx / RG);
+  return (ty / rg.rg) * rg.regions_x + (tx / rg.rg);
 }
 
 // K1: per-workgroup region populations, written to part[region][workgroup] (no global atomics:
@@ -275,18 +278,22 @@ __global__ __launch_bounds__(256) void region_part_scan_kernel(int num_wg, int* 
 
 // K2b: exclusive scan of the region populations -> start of each region in the ordered list, and of
 // the per-region chunk counts (a chunk = up to 256 Gaussians of ONE region = one workgroup later on).
-__global__ __launch_bounds__(64) void region_scan_kernel(int num_regions, const int* region_count, int* region_start,
-                                                         int* chunk_start) {
-  if (threadIdx.x == 0) {
-    int acc = 0, chunks = 0;
-    for (int r = 0; r < num_regions; ++r) {
-      region_start[r] = acc;
-      chunk_start[r] = chunks;
-      acc += region_count[r];
-      chunks += (region_count[r] + 255) >> 8;
-    }
-    region_start[num_regions] = acc;
-    chunk_start[num_regions] = chunks;
+__global__ __launch_bounds__(1024) void region_scan_kernel(int num_regions, const int* region_count, int* region_start,
+                                                           int* chunk_start) {
+  __shared__ int s_wave[16];
+  const int r = threadIdx.x;  // num_regions <= MAX_REGIONS = 1024
+  const int c = r < num_regions ? region_count[r] : 0;
+  const int ch = (c + 255) >> 8;
+  int total_c, total_ch;
+  const int start = block_exclusive_scan(c, s_wave, total_c);
+  const int chunk = block_exclusive_scan(ch, s_wave, total_ch);
+  if (r < num_regions) {
+    region_start[r] = start;
+    chunk_start[r] = chunk;
+  }
+  if (r == 0) {
+    region_start[num_regions] = total_c;
+    chunk_start[num_regions] = total_ch;
   }
 }
 
@@ -337,12 +344,13 @@ __device__ __forceinline__ bool locate_chunk(int block, const RegionGrid& rg, co
 __global__ __launch_bounds__(256) void count_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                            const int* region_start, const int* chunk_start,
                                                            int* tile_hist) {
-  __shared__ int s_win[WIN_TILES];
+  extern __shared__ int s_win[];  // win * win
+  const int WIN = rg.win, WIN_TILES = WIN * WIN;
   int region, first, count;
   if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
   for (int e = threadIdx.x; e < WIN_TILES; e += 256) s_win[e] = 0;
   __syncthreads();
-  const int wx0 = (region % rg.regions_x) * RG - RB, wy0 = (region / rg.regions_x) * RG - RB;
+  const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
   if (int(threadIdx.x) < count) {
     const int i = order[first + threadIdx.x];
     const GridQuery q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
@@ -372,13 +380,15 @@ __global__ __launch_bounds__(256) void count_binned_kernel(MapArgs a, RegionGrid
 __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                           const int* region_start, const int* chunk_start,
                                                           int* cursors, uint64_t* pairs) {
-  __shared__ int s_cnt[WIN_TILES];
-  __shared__ int s_base[WIN_TILES];
+  extern __shared__ int s_dyn[];  // 2 * win * win
+  const int WIN = rg.win, WIN_TILES = WIN * WIN;
+  int* s_cnt = s_dyn;
+  int* s_base = s_dyn + WIN_TILES;
   int region, first, count;
   if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
   for (int e = threadIdx.x; e < WIN_TILES; e += 256) s_cnt[e] = 0;
   __syncthreads();
-  const int wx0 = (region % rg.regions_x) * RG - RB, wy0 = (region / rg.regions_x) * RG - RB;
+  const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
   const bool active = int(threadIdx.x) < count;
   GridQuery q;
   q.span_x = q.span_y = 0;
@@ -721,8 +731,7 @@ struct MapScratch {
   int* hist; int* cursors; int* region_of; int* order; int* region_count; int* region_start; int* part;
   int* chunk_start;
 };
-// part[region][workgroup]; the region count is bounded by the tile count (RG x RG tiles per region,
-// at least one region per RG tiles along each axis)
+// part[region][workgroup]; the region count is bounded by the tile count and by MAX_REGIONS
 int64_t part_entries(int64_t v, int64_t num_tiles) {
   const int64_t regions = num_tiles < MAX_REGIONS ? (num_tiles < 1 ? 1 : num_tiles) : MAX_REGIONS;
   return regions * gs_div_up(v > 0 ? v : 1, 256);
@@ -745,8 +754,11 @@ RegionGrid make_grid(const MapArgs& a) {
   RegionGrid rg;
   rg.tiles_x = a.tiles_wide;
   rg.tiles_y = a.Hp / a.tile_size;
-  rg.regions_x = int(gs_div_up(rg.tiles_x, RG));
-  rg.num_regions = rg.regions_x * int(gs_div_up(rg.tiles_y, RG));
+  rg.rg = RG_MIN;
+  while (gs_div_up(rg.tiles_x, rg.rg) * gs_div_up(rg.tiles_y, rg.rg) > MAX_REGIONS) rg.rg *= 2;
+  rg.win = rg.rg + 2 * RB;
+  rg.regions_x = int(gs_div_up(rg.tiles_x, rg.rg));
+  rg.num_regions = rg.regions_x * int(gs_div_up(rg.tiles_y, rg.rg));
   return rg;
 }
 }  // namespace
@@ -774,7 +786,9 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   int* hist = m.hist;
   int* cursors = m.cursors;
   const RegionGrid rg = make_grid(a);
-  GS_REQUIRE(rg.num_regions <= MAX_REGIONS, GS_ERR_UNSUPPORTED, "gs_map_prepare: %d regions", rg.num_regions);
+  GS_REQUIRE(rg.num_regions <= MAX_REGIONS && rg.win * rg.win * 8 <= 65536, GS_ERR_UNSUPPORTED,
+             "gs_map_prepare: tile grid %dx%d needs %d regions of edge %d", rg.tiles_x, rg.tiles_y, rg.num_regions,
+             rg.rg);
   const bool ok = hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) == hipSuccess;
   if (!ok) {
     gs_set_error("gs_map_prepare: hipMemsetAsync failed");
@@ -786,12 +800,13 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
     hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part);
     hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(256), 0, s, int(vb), m.part,
                        m.region_count);
-    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(64), 0, s, rg.num_regions, m.region_count, m.region_start,
+    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,
                        m.chunk_start);
     hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part,
                        m.region_start, m.order);
     // one workgroup per chunk of <= 256 Gaussians of one region; surplus workgroups exit at once
-    hipLaunchKernelGGL(count_binned_kernel, dim3(vb + unsigned(rg.num_regions)), dim3(256), 0, s, a, rg, m.order,
+    hipLaunchKernelGGL(count_binned_kernel, dim3(vb + unsigned(rg.num_regions)), dim3(256),
+                       size_t(rg.win) * rg.win * 4, s, a, rg, m.order,
                        m.region_start, m.chunk_start, hist);
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
@@ -821,7 +836,8 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
   const RegionGrid rg = make_grid(a);
   uint64_t* pairs = static_cast<uint64_t*>(pair_scratch);
   // the region ordering left in scratch by gs_map_prepare is reused here
-  hipLaunchKernelGGL(emit_binned_kernel, dim3(unsigned(gs_div_up(v, 256)) + unsigned(rg.num_regions)), dim3(256), 0, s,
+  hipLaunchKernelGGL(emit_binned_kernel, dim3(unsigned(gs_div_up(v, 256)) + unsigned(rg.num_regions)), dim3(256),
+                     size_t(rg.win) * rg.win * 8, s,
                      a, rg, m.order, m.region_start, m.chunk_start, cursors, pairs);
   GS_CHECK_LAUNCH("gs_map_finish/emit");
   const int grid = 8 * int(gs_div_up(num_tiles, 8));

@@ -153,6 +153,8 @@ class _FusedRender(torch.autograd.Function):
         ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, full_h=full_h, F=F, C=C, col0=col0, degree=degree, config=config,
                         render_depth=render_depth, group=group, sharded=strip is not None)
         ctx.heur = heur
+        # outputs nobody differentiates through (projected splats, depths) must not cost zero-filled gradients
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
                               indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth, tile_order)
         ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur)
