@@ -14,7 +14,8 @@ from ctypes import POINTER, c_double, c_float, c_int32, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsplat_hip.so")
+# GS_LIB_PATH: developer override to A/B two builds of the library in one session (tools/ab_lib.sh)
+LIB_PATH = os.environ.get("GS_LIB_PATH") or os.path.join(_HERE, "libgsplat_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 

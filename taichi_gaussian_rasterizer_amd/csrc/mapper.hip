@@ -204,6 +204,10 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
 constexpr int RG_MIN = 8;              // smallest region edge in tiles
 constexpr int RB = 4;                  // window border in tiles (splats reaching further fall back to global atomics)
 constexpr int MAX_REGIONS = 1024;
+#ifndef GS_MAP_CHUNK
+#define GS_MAP_CHUNK 512
+#endif
+constexpr int CHUNK = GS_MAP_CHUNK;     // Gaussians (= threads) per counting / bucketing workgroup
 
 struct RegionGrid {
   int tiles_x, tiles_y, regions_x, num_regions;
@@ -277,13 +281,13 @@ __global__ __launch_bounds__(256) void region_part_scan_kernel(int num_wg, int* 
 }
 
 // K2b: exclusive scan of the region populations -> start of each region in the ordered list, and of
-// the per-region chunk counts (a chunk = up to 256 Gaussians of ONE region = one workgroup later on).
+// the per-region chunk counts (a chunk = up to CHUNK Gaussians of ONE region = one workgroup later on).
 __global__ __launch_bounds__(1024) void region_scan_kernel(int num_regions, const int* region_count, int* region_start,
                                                            int* chunk_start) {
   __shared__ int s_wave[16];
   const int r = threadIdx.x;  // num_regions <= MAX_REGIONS = 1024
   const int c = r < num_regions ? region_count[r] : 0;
-  const int ch = (c + 255) >> 8;
+  const int ch = (c + CHUNK - 1) / CHUNK;
   int total_c, total_ch;
   const int start = block_exclusive_scan(c, s_wave, total_c);
   const int chunk = block_exclusive_scan(ch, s_wave, total_ch);
@@ -328,8 +332,8 @@ __device__ __forceinline__ bool locate_chunk(int block, const RegionGrid& rg, co
       }
       r = lo;
       const int c = block - chunk_start[r];
-      s_loc[1] = region_start[r] + c * 256;
-      s_loc[2] = min(256, region_start[r + 1] - s_loc[1]);
+      s_loc[1] = region_start[r] + c * CHUNK;
+      s_loc[2] = min(CHUNK, region_start[r + 1] - s_loc[1]);
     }
     s_loc[0] = r;
   }
@@ -341,14 +345,14 @@ __device__ __forceinline__ bool locate_chunk(int block, const RegionGrid& rg, co
 }
 
 // K4: per-tile histogram through the LDS window.
-__global__ __launch_bounds__(256) void count_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
+__global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                            const int* region_start, const int* chunk_start,
                                                            int* tile_hist) {
   extern __shared__ int s_win[];  // win * win
   const int WIN = rg.win, WIN_TILES = WIN * WIN;
   int region, first, count;
   if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
-  for (int e = threadIdx.x; e < WIN_TILES; e += 256) s_win[e] = 0;
+  for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) s_win[e] = 0;
   __syncthreads();
   const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
   if (int(threadIdx.x) < count) {
@@ -364,7 +368,7 @@ __global__ __launch_bounds__(256) void count_binned_kernel(MapArgs a, RegionGrid
         }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < WIN_TILES; e += 256) {
+  for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) {
     const int c = s_win[e];
     if (c > 0) {
       const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(256) void count_binned_kernel(MapArgs a, RegionGrid
 // contiguous range per window tile with a single returning global atomic, pass C places the pairs
 // with LDS atomics.  The accepted-tile set of a lane is kept as a 64-bit mask between the passes
 // when its candidate span fits (<= 64 tiles), so the OBB tests run once.
-__global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
+__global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                           const int* region_start, const int* chunk_start,
                                                           int* cursors, uint64_t* pairs) {
   extern __shared__ int s_dyn[];  // 2 * win * win
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid 
   int* s_base = s_dyn + WIN_TILES;
   int region, first, count;
   if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
-  for (int e = threadIdx.x; e < WIN_TILES; e += 256) s_cnt[e] = 0;
+  for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) s_cnt[e] = 0;
   __syncthreads();
   const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
   const bool active = int(threadIdx.x) < count;
@@ -409,7 +413,7 @@ __global__ __launch_bounds__(256) void emit_binned_kernel(MapArgs a, RegionGrid 
         }
   }
   __syncthreads();
-  for (int e = threadIdx.x; e < WIN_TILES; e += 256) {
+  for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) {
     const int c = s_cnt[e];
     if (c > 0) {
       const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
@@ -804,8 +808,8 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
                        m.chunk_start);
     hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part,
                        m.region_start, m.order);
-    // one workgroup per chunk of <= 256 Gaussians of one region; surplus workgroups exit at once
-    hipLaunchKernelGGL(count_binned_kernel, dim3(vb + unsigned(rg.num_regions)), dim3(256),
+    // one workgroup per chunk of <= CHUNK Gaussians of one region; surplus workgroups exit at once
+    hipLaunchKernelGGL(count_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
                        size_t(rg.win) * rg.win * 4, s, a, rg, m.order,
                        m.region_start, m.chunk_start, hist);
     GS_CHECK_LAUNCH("gs_map_prepare/count");
@@ -836,7 +840,7 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
   const RegionGrid rg = make_grid(a);
   uint64_t* pairs = static_cast<uint64_t*>(pair_scratch);
   // the region ordering left in scratch by gs_map_prepare is reused here
-  hipLaunchKernelGGL(emit_binned_kernel, dim3(unsigned(gs_div_up(v, 256)) + unsigned(rg.num_regions)), dim3(256),
+  hipLaunchKernelGGL(emit_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
                      size_t(rg.win) * rg.win * 8, s,
                      a, rg, m.order, m.region_start, m.chunk_start, cursors, pairs);
   GS_CHECK_LAUNCH("gs_map_finish/emit");
