@@ -535,6 +535,43 @@ def test_fused_frame_equals_composed_operators(depth_mode, heur):
             pu.assert_grad_close(r.point_heuristic, r2.point_heuristic, "heuristic", tol=1e-4)
 
 
+@pytest.mark.parametrize("depth_mode", [False, True])
+def test_fused_frame_gradients_through_projected_splats(depth_mode):
+    """a loss that also reads `gaussians2d` and `point_depth` (a regulariser on the projected splats): the fused
+    node adds those upstream gradients to the rasterizer's rows; unused outputs get no materialized zeros"""
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    size, n = (192, 128), 5000
+    cfg = RasterConfig()
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=2, seed=11)
+    cam = camera.to(device=DEV)
+    gen = torch.Generator().manual_seed(5)
+    gi = dev(torch.rand(size[1], size[0], 3, generator=gen))
+    grads = []
+    for fused_path in (True, False):
+        a = g.to(DEV).requires_grad_(True)
+        if fused_path:
+            r = gs.render_gaussians(a, cam, cfg, use_sh=True, render_depth=depth_mode)
+        else:
+            g2d, depths, idx, ndc = hip_proj.project_with_ndc(*a.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                              cam.image_size, cam.depth_range, cfg)
+            feats = gs.evaluate_sh_at(a.feature, a.position.detach(), idx, cam.camera_position)
+            r = render_projected(idx, g2d, feats, depths, cam, cfg, render_depth=depth_mode, ndc_depths=ndc)
+        V = r.gaussians2d.shape[0]
+        w2d = dev(torch.rand(V, 7, generator=torch.Generator().manual_seed(6)))
+        wd = dev(torch.rand(V, generator=torch.Generator().manual_seed(7)))
+        loss = (r.image * gi).sum() + 0.01 * (r.gaussians2d * w2d).sum() + 0.1 * (r.point_depth.reshape(-1) * wd).sum()
+        loss.backward()
+        grads.append({k: t.grad.clone() for k, t in a.items()})
+    for k in grads[0]:
+        pu.assert_grad_close(grads[0][k], grads[1][k], f"fused grad {k} with splat/depth terms", tol=1e-4)
+    # only the splats are used: no image gradient at all
+    a = g.to(DEV).requires_grad_(True)
+    r = gs.render_gaussians(a, cam, cfg, use_sh=True, render_depth=depth_mode)
+    r.gaussians2d.sum().backward()
+    assert a.position.grad is not None and torch.isfinite(a.position.grad).all()
+    assert a.feature.grad is None or float(a.feature.grad.abs().max()) == 0.0
+
+
 def test_fused_frame_capacity_overflow_rerun():
     from taichi_gaussian_rasterizer_amd import fused
     size, n = (256, 192), 8000
