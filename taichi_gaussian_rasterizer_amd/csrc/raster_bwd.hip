@@ -38,7 +38,7 @@ struct BwdArgs {
   int row_floats;
   int tiles_wide;
   int tile_size;
-  int sub;
+  int sub_x, sub_y;  // wave regions per tile along x / y
   int num_items;
   const int* tile_order;  // optional launch order of the items (heaviest first)
   float cmax, thr, sat;
@@ -62,7 +62,7 @@ template <int NB, int FP, bool FULL>
 __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
   // launch order: heaviest tiles first when the mapper supplied an order (shortens the tail of the
   // launch: a tile's cost is proportional to its splat count), else XCD-contiguous bands
-  const int per_tile = a.sub * a.sub;
+  const int per_tile = a.sub_x * a.sub_y;
   int item;
   if (a.tile_order) {
     if (int(blockIdx.x) >= a.num_items) return;
@@ -73,9 +73,9 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   }
   const int lane = threadIdx.x;
   const int tile = item / per_tile, quad = item - tile * per_tile;
-  const int region = NB == 1 ? 8 : 16;
-  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub) * region;
-  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub) * region;
+  constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
+  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
+  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
 
   constexpr int NS = FULL ? 9 : 6;        // lean: 6 moment sums; full: 7 gradients + 2 heuristics
@@ -390,14 +390,18 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.row_floats = gs_grad_row_floats(num_features);
   a.tiles_wide = int(gs_div_up(width, ts));
   a.tile_size = ts;
-  a.sub = ts == 32 ? 2 : 1;
-  a.num_items = a.tiles_wide * int(gs_div_up(height, ts)) * a.sub * a.sub;
+  const int num_tiles = a.tiles_wide * int(gs_div_up(height, ts));
+  const int nb = gs_raster_sub_blocks(ts, num_tiles);
+  a.sub_x = ts / (nb == 1 ? 8 : 16);
+  a.sub_y = ts / (nb == 4 ? 16 : 8);
+  a.num_items = num_tiles * a.sub_x * a.sub_y;
   a.tile_order = tile_order;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool full = a.aa || a.heur;
-  if (ts == 8) return full ? launch_fp<1, true>(a, s) : launch_fp<1, false>(a, s);
+  if (nb == 1) return full ? launch_fp<1, true>(a, s) : launch_fp<1, false>(a, s);
+  if (nb == 2) return full ? launch_fp<2, true>(a, s) : launch_fp<2, false>(a, s);
   return full ? launch_fp<4, true>(a, s) : launch_fp<4, false>(a, s);
 }
 
