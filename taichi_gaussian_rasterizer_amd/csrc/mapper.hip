@@ -225,12 +225,15 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
 
 // K1: per-workgroup region populations, written to part[region][workgroup] (no global atomics:
 // thousands of workgroups adding into a handful of counters would serialise on one line).
-__global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
+// BIN Gaussians per workgroup: the part matrix has num_regions * ceil(V / BIN) entries, so a large BIN keeps
+// it (and its scan) small next to the V-entry arrays.
+constexpr int BIN = 1024;
+__global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
                                                            int* part) {
   __shared__ int s_hist[MAX_REGIONS];
-  for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_hist[r] = 0;
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
   __syncthreads();
-  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
   if (i < live_count(a)) {
     // Gaussians that touch no tile at all (off-screen within the cull margin; above or below this
     // rank's strip when the frame is sharded) are left out of the ordering, so the counting and
@@ -250,32 +253,21 @@ __global__ __launch_bounds__(256) void region_count_kernel(MapArgs a, RegionGrid
     if (r >= 0) atomicAdd(&s_hist[r], 1);
   }
   __syncthreads();
-  for (int r = threadIdx.x; r < rg.num_regions; r += 256) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
 }
 
 // K2a: one workgroup per region: exclusive scan of part[region][*] in place, total -> region_count.
-__global__ __launch_bounds__(256) void region_part_scan_kernel(int num_wg, int* part, int* region_count) {
-  __shared__ int s[256];
-  __shared__ int carry;
+__global__ __launch_bounds__(1024) void region_part_scan_kernel(int num_wg, int* part, int* region_count) {
+  __shared__ int s_wave[16];
   int* row = part + int64_t(blockIdx.x) * num_wg;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < num_wg; base += 256) {
+  int carry = 0;
+  for (int base = 0; base < num_wg; base += 1024) {
     const int i = base + threadIdx.x;
     const int v = i < num_wg ? row[i] : 0;
-    s[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-      int x = s[threadIdx.x];
-      if (threadIdx.x >= off) x += s[threadIdx.x - off];
-      __syncthreads();
-      s[threadIdx.x] = x;
-      __syncthreads();
-    }
-    if (i < num_wg) row[i] = carry + s[threadIdx.x] - v;
-    __syncthreads();
-    if (threadIdx.x == 255) carry += s[255];
-    __syncthreads();
+    int total;
+    const int before = block_exclusive_scan(v, s_wave, total);
+    if (i < num_wg) row[i] = carry + before;
+    carry += total;
   }
   if (threadIdx.x == 0) region_count[blockIdx.x] = carry;
 }
@@ -303,12 +295,12 @@ __global__ __launch_bounds__(1024) void region_scan_kernel(int num_regions, cons
 
 // K3: write the Gaussian indices grouped by region: position = region start + this workgroup's
 // offset inside the region (K2a) + rank inside the workgroup (LDS atomic).
-__global__ __launch_bounds__(256) void region_scatter_kernel(MapArgs a, RegionGrid rg, int num_wg, const int* region_of,
+__global__ __launch_bounds__(BIN) void region_scatter_kernel(MapArgs a, RegionGrid rg, int num_wg, const int* region_of,
                                                              const int* part, const int* region_start, int* order) {
   __shared__ int s_cnt[MAX_REGIONS];
-  for (int r = threadIdx.x; r < rg.num_regions; r += 256) s_cnt[r] = 0;
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_cnt[r] = 0;
   __syncthreads();
-  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
   if (i < live_count(a)) {
     const int r = region_of[i];
     if (r >= 0) {
@@ -738,7 +730,7 @@ struct MapScratch {
 // part[region][workgroup]; the region count is bounded by the tile count and by MAX_REGIONS
 int64_t part_entries(int64_t v, int64_t num_tiles) {
   const int64_t regions = num_tiles < MAX_REGIONS ? (num_tiles < 1 ? 1 : num_tiles) : MAX_REGIONS;
-  return regions * gs_div_up(v > 0 ? v : 1, 256);
+  return regions * gs_div_up(v > 0 ? v : 1, BIN);
 }
 MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
   char* p = static_cast<char*>(scratch);
@@ -800,13 +792,13 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   }
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
-    const unsigned vb = unsigned(gs_div_up(v, 256));
-    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part);
-    hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(256), 0, s, int(vb), m.part,
+    const unsigned vb = unsigned(gs_div_up(v, BIN));
+    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part);
+    hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
                        m.region_count);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,
                        m.chunk_start);
-    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(256), 0, s, a, rg, int(vb), m.region_of, m.part,
+    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part,
                        m.region_start, m.order);
     // one workgroup per chunk of <= CHUNK Gaussians of one region; surplus workgroups exit at once
     hipLaunchKernelGGL(count_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
