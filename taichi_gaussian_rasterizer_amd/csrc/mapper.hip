@@ -152,20 +152,31 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   s_bin[t] = 0;
   __syncthreads();
   int carry = 0, mx = 0;
-  for (int base = 0; base < num_tiles; base += 1024) {
-    const int i = base + t;
-    const int c = i < num_tiles ? tile_hist[i] : 0;
-    mx = max(mx, c);
-    if (tile_order && i < num_tiles) atomicAdd(&s_bin[min(c, 1023)], 1);
-    int total;
-    const int run = carry + block_exclusive_scan(c, s_wave, total);
-    carry += total;
-    if (i < num_tiles) {
-      // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
-      // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
-      const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
-      tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
-      cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
+  constexpr int U = 8;  // rounds whose loads are issued together (a load behind every barrier would cost its latency each)
+  for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
+    int cs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base0 + u * 1024 + t;
+      cs[u] = i < num_tiles ? tile_hist[i] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base0 + u * 1024 + t;
+      if (base0 + u * 1024 >= num_tiles) break;  // uniform
+      const int c = cs[u];
+      mx = max(mx, c);
+      if (tile_order && i < num_tiles) atomicAdd(&s_bin[min(c, 1023)], 1);
+      int total;
+      const int run = carry + block_exclusive_scan(c, s_wave, total);
+      carry += total;
+      if (i < num_tiles) {
+        // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
+        // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
+        const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
+        tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
+        cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
+      }
     }
   }
   // fullest tile
@@ -257,8 +268,11 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
 }
 
 // K2a: one workgroup per region: exclusive scan of part[region][*] in place, total -> region_count.
-__global__ __launch_bounds__(1024) void region_part_scan_kernel(int num_wg, int* part, int* region_count) {
+__global__ __launch_bounds__(1024) void region_part_scan_kernel(int num_wg, int* part, int* region_count,
+                                                                int* tile_hist, int num_tiles) {
   __shared__ int s_wave[16];
+  // also clears the tile histogram the counting pass adds into (saves a memset launch)
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < num_tiles; i += gridDim.x * 1024) tile_hist[i] = 0;
   int* row = part + int64_t(blockIdx.x) * num_wg;
   int carry = 0;
   for (int base = 0; base < num_wg; base += 1024) {
@@ -785,8 +799,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   GS_REQUIRE(rg.num_regions <= MAX_REGIONS && rg.win * rg.win * 8 <= 65536, GS_ERR_UNSUPPORTED,
              "gs_map_prepare: tile grid %dx%d needs %d regions of edge %d", rg.tiles_x, rg.tiles_y, rg.num_regions,
              rg.rg);
-  const bool ok = hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) == hipSuccess;
-  if (!ok) {
+  if (v == 0 && hipMemsetAsync(hist, 0, size_t(num_tiles) * 4, s) != hipSuccess) {
     gs_set_error("gs_map_prepare: hipMemsetAsync failed");
     return GS_ERR_LAUNCH;
   }
@@ -795,7 +808,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
     const unsigned vb = unsigned(gs_div_up(v, BIN));
     hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part);
     hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
-                       m.region_count);
+                       m.region_count, hist, num_tiles);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,
                        m.chunk_start);
     hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part,
