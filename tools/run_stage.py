@@ -22,6 +22,6 @@ for _ in range(frames):
         t.grad = None
     r = gs.render_gaussians(g, cam, RasterConfig(), use_sh=True, render_depth=wl["depth"])
     if wl["backward"]:
-        (r.image * G).sum().backward()
+        r.image.backward(G)
 torch.cuda.synchronize()
 print("done", int(r.points_in_view.shape[0]))
