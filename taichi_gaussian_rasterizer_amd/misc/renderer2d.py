@@ -25,3 +25,29 @@ def render_gaussians(gaussians: Gaussians2D, image_size: Tuple[Integral, Integra
     gaussians2d = project_gaussians2d(gaussians)
     return rasterize(gaussians2d=gaussians2d, depth=torch.clamp(gaussians.z_depth, 0, 1),
                      features=gaussians.feature, image_size=image_size, config=raster_config)
+
+
+def _unit_axes(points: Gaussians2D):
+    major = torch.nn.functional.normalize(points.rotation, dim=1)
+    minor = torch.stack([-major[:, 1], major[:, 0]], dim=-1)
+    return major, minor
+
+
+def point_basis(points: Gaussians2D, eps: float = 1e-4) -> torch.Tensor:
+    """(N,2,2) local frame of every Gaussian: columns = unit axes scaled by sigma (reference
+    misc/renderer2d.py:37-43); the `basis` of the local_vector optimizer groups."""
+    major, minor = _unit_axes(points)
+    sigma = points.scaling.clamp_min(eps)
+    return torch.stack([major, minor], dim=2) * sigma.unsqueeze(-2)
+
+
+def point_rotation(points: Gaussians2D) -> torch.Tensor:
+    """(N,2,2) rows = unit major / minor axis (reference misc/renderer2d.py:47-52)."""
+    major, minor = _unit_axes(points)
+    return torch.stack([major, minor], dim=1)
+
+
+def point_covariance(points: Gaussians2D) -> torch.Tensor:
+    """(N,2,2) covariance B B^T (reference misc/renderer2d.py:54-56)."""
+    basis = point_basis(points)
+    return basis @ basis.transpose(1, 2)

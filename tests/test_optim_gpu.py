@@ -85,3 +85,45 @@ def test_sparse_adam_against_torch_adam():
     lp.step(torch.tensor([1, 7], device=dev))
     changed = (ours.detach() != before).any(1).nonzero().flatten().tolist()
     assert changed == [1, 7]
+
+
+def test_fit_image_loop_with_visibility_aware_laprop():
+    """the reference example's training step (examples/fit_image_gaussians.py:87-137, parameter groups :266-279):
+    rasterize -> loss -> backward -> VisibilityAwareLaProp.step(visible, visibility, basis) with a local_vector
+    position group, then rotation renormalised; the loss has to go down"""
+    import taichi_gaussian_rasterizer_amd as gs
+    from taichi_gaussian_rasterizer_amd import RasterConfig, scenes
+    from taichi_gaussian_rasterizer_amd.misc.renderer2d import point_basis, project_gaussians2d
+    from taichi_gaussian_rasterizer_amd.optim import VisibilityAwareLaProp
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    n, size = 2000, (256, 256)
+    w, h = size
+    g = scenes.random_2d_gaussians(n, size, alpha_range=(0.5, 1.0), scale_factor=0.5).to(dev)
+    target = torch.rand(h // 16, w // 16, 3, generator=torch.Generator().manual_seed(1))
+    target = torch.nn.functional.interpolate(target.permute(2, 0, 1)[None], size=(h, w), mode='bilinear')[0]
+    target = target.permute(1, 2, 0).contiguous().to(dev)
+    params = {k: torch.nn.Parameter(v.clone()) for k, v in g.items() if k != 'z_depth'}
+    z_depth = g.z_depth
+    groups = [dict(params=[params['position']], name='position', lr=0.5, type='local_vector'),
+              dict(params=[params['log_scaling']], name='log_scaling', lr=0.1),
+              dict(params=[params['rotation']], name='rotation', lr=1.0),
+              dict(params=[params['alpha_logit']], name='alpha_logit', lr=0.1),
+              dict(params=[params['feature']], name='feature', lr=0.1, type='vector')]
+    opt = VisibilityAwareLaProp(groups, vis_smooth=0.1, vis_beta=0.8, betas=(0.9, 0.9), eps=1e-16, bias_correction=True)
+    cfg = RasterConfig(compute_point_heuristic=True, compute_visibility=True, blur_cov=0.3)
+    losses = []
+    for _ in range(25):
+        opt.zero_grad()
+        gg = type(g)(**params, z_depth=z_depth, batch_size=(n,))
+        raster = gs.rasterize(project_gaussians2d(gg), gg.z_depth.clamp(0, 1), gg.feature, size, cfg)
+        loss = torch.nn.functional.mse_loss(raster.image.sigmoid(), target)
+        loss.backward()
+        visibility = raster.visibility
+        visible = (visibility > 1e-8).nonzero().squeeze(1)
+        opt.step(indexes=visible, visibility=visibility[visible], basis=point_basis(gg[visible]))
+        with torch.no_grad():
+            params['rotation'].copy_(torch.nn.functional.normalize(params['rotation']))
+        losses.append(float(loss.detach()))
+    assert all(torch.isfinite(p).all() for p in params.values())
+    assert losses[-1] < 0.7 * losses[0], losses
