@@ -8,12 +8,14 @@
 //
 // Fused path (gs_map_prepare / gs_map_finish), designed for MI355X rather than around a
 // library radix sort:
-//   bin     : order the Gaussians by the screen region (32x32 tiles) of their centre -- LDS
-//             histograms + a per-region scan over workgroups, no global atomics.
+//   bin     : order the Gaussians by the screen region (8x8 tiles; larger when the image has more than
+//             1024 of them) of their centre -- LDS histograms + a per-region scan over workgroups, no
+//             global atomics.
 //   count   : 1 lane per Gaussian, OBB query; overlaps are counted in an LDS window over the
-//             workgroup's region (+ border) and flushed with row-contiguous atomics into a T-entry
+//             workgroup's region (+ border) and flushed with one atomic per window tile into a T-entry
 //             histogram (scattered 4-B global atomics only reach ~20 G/s on MI355X).
-//   scan    : single workgroup exclusive scan of the histogram -> tile_ranges, cursors, K, max.
+//   scan    : single workgroup exclusive scan of the histogram -> tile_ranges, cursors, K, max, and the
+//             rasterizer's launch order (tiles by descending population).
 //   emit    : the query again; one returning atomic per (workgroup, tile) reserves a range of the
 //             tile's bucket, LDS atomics place the 64-bit composites (depth key << 32 | index).
 //   sort    : one wave per tile rank-sorts its bucket (bitonic in LDS / global for crowded tiles).
@@ -204,11 +206,9 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
 // ---- region-binned counting / bucketing --------------------------------------------------
 // Scattered 4-byte global atomics run at only ~20 G/s on MI355X (every one is its own 64-B
 // memory-side request), which made the plain count / emit kernels above atomic-bound (K atomics
-// each).  The binned path first orders the Gaussians by the screen REGION of their centre (a region
-// is RG x RG tiles; a handful of regions, so the binning itself needs only a few atomics per
-// workgroup), then lets every workgroup -- whose 256 Gaussians now share one region -- count its
-// overlaps in an LDS window covering the region plus a border, and touch global memory once per
-// window tile with row-contiguous (coalescing) atomics: ~12x fewer atomic requests.
+// each).  The binned path first orders the Gaussians by the screen REGION of their centre, then lets
+// every workgroup -- whose CHUNK Gaussians now share one region -- count its overlaps in an LDS window
+// covering the region plus a border, and touch global memory once per window tile.
 // The region edge is the smallest power of two >= RG_MIN that keeps the region count <= MAX_REGIONS: the
 // smaller the region, the more of a workgroup's overlaps share a window tile, i.e. the fewer global atomics
 // (8x8-tile regions: ~5 overlaps per atomic at 256 Gaussians per workgroup; 32x32: ~1.4).
