@@ -124,6 +124,30 @@ def test_raster_forward_backward(seed, n, size, tile, F):
     pu.assert_grad_close(f_t.grad, gf, "grad_features")
 
 
+@pytest.mark.parametrize("nb", [1, 2, 4])
+@pytest.mark.parametrize("seed,n,size,tile,F", [(11, 3000, (200, 120), 16, 3), (12, 2000, (160, 96), 32, 5)])
+def test_raster_wave_region_variants(nb, seed, n, size, tile, F, monkeypatch):
+    """the rasterizer picks 16x16, 16x8 or 8x8 pixel regions per wave from the grid size (gs_raster_sub_blocks);
+    GS_RASTER_NB forces each variant on the same scene: all must agree with the oracle"""
+    monkeypatch.setenv("GS_RASTER_NB", str(nb))
+    g2d, depth, feat = pu.make_2d_scene(seed, n, size, channels=F, scale_factor=0.5)
+    cfg = RasterConfig(tile_size=tile, compute_visibility=(nb == 2))
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)
+    image_ref, alpha_ref, vis_ref = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
+    pu.assert_pixels_close(out.image, image_ref, "image")
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    if cfg.compute_visibility:
+        pu.assert_grad_close(out.visibility, vis_ref, "visibility", tol=1e-5)
+    gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(seed))
+    (out.image * dev(gi)).sum().backward()
+    gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d")
+    pu.assert_grad_close(f_t.grad, gf, "grad_features")
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_raster_reference_gradcheck_scene(seed):
     """the reference's own rasterizer test scene (tests/test_rasterizer.py:30-59), f32 vs oracle f64"""
