@@ -244,10 +244,15 @@ int gs_morton_codes64(int64_t n, const float* points, const float* lower_host, f
  * moments m, v of row idx in place and write lr_step (rows, dims).  laprop: 0 = Adam, 1 = LaProp;
  * vector_group: 0 = per-element second moment v (N,dims), 1 = one v per row (N) from |g|^2.
  * m (N,dims), total_weight (N), grad (N,dims).
+ * Optional fusions (each may be NULL): row_scale (rows) multiplies the gradient of visible row i
+ * (optim/visibility_aware.py:100-103); param (N,dims) applies the step in place,
+ * param[idx] -= lr_step * (1 - exp(-2 weight)) * mask_lr[j] * point_lr[idx] (optim/fractional.py:31-32, :57-63,
+ * :139-146; mask_lr (dims), point_lr (N) optional), in which case lr_step itself may be NULL.
  */
 int gs_optim_step(int32_t laprop, int32_t vector_group, int64_t rows, int32_t dims, const int64_t* indexes,
                   const float* weight, float* m, float* v, const float* total_weight, const float* grad, float lr,
-                  float beta1, float beta2, float eps, int32_t bias_correction, float* lr_step, void* stream);
+                  float beta1, float beta2, float eps, int32_t bias_correction, float* lr_step,
+                  const float* row_scale, float* param, const float* mask_lr, const float* point_lr, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,16 @@ struct OptArgs {
   int dims;
   float lr, beta1, beta2, eps;
   int bias_correction;
+  // optional fusions of what follows / precedes the moment update in FractionalOpt.step (optim/fractional.py:36-63)
+  // and VisibilityOptimizer.step (optim/visibility_aware.py:85-108):
+  const float* row_scale;  // (rows): the gradient of visible row i is multiplied by row_scale[i] first
+  float* param;            // (N,dims): param[idx] -= step * saturate(weight) [* mask_lr[j]] [* point_lr[idx]]
+  const float* mask_lr;    // (dims) or null
+  const float* point_lr;   // (N) or null
 };
+
+// 1 - exp(-2 w) (optim/fractional.py:31-32), without cancellation for small w
+__device__ __forceinline__ float saturate_weight(float w) { return -expm1f(-2.0f * w); }
 
 // 1 - beta^t without the cancellation the literal form has for small t (beta2 = 0.999, t < 1 leaves ~3 digits in f32)
 __device__ __forceinline__ float one_minus_pow(float beta, float t) { return -expm1f(t * logf(beta)); }
@@ -45,7 +54,7 @@ __global__ __launch_bounds__(256) void optim_scalar_kernel(OptArgs a) {
   const int64_t idx = a.indexes[i];
   const float w = a.weight[i], tw = a.total_weight[idx];
   const int64_t at = idx * a.dims + j;
-  const float g = a.grad[at];
+  const float g = a.row_scale ? a.grad[at] * a.row_scale[i] : a.grad[at];
   float m, v, step;
   if (LAPROP) {
     const float bias1 = a.bias_correction ? one_minus_pow(a.beta1, tw) : 1.0f;
@@ -59,9 +68,15 @@ __global__ __launch_bounds__(256) void optim_scalar_kernel(OptArgs a) {
     v = lerp_pow(a.beta2, w, a.v[at], g * g);
     step = m / fmaxf(sqrtf(v), a.eps) * bias * a.lr;
   }
-  a.lr_step[e] = step;
+  if (a.lr_step) a.lr_step[e] = step;
   a.m[at] = m;
   a.v[at] = v;
+  if (a.param) {
+    float upd = step * saturate_weight(w);
+    if (a.mask_lr) upd *= a.mask_lr[j];
+    if (a.point_lr) upd *= a.point_lr[idx];
+    a.param[at] -= upd;
+  }
 }
 
 template <bool LAPROP>
@@ -70,25 +85,35 @@ __global__ __launch_bounds__(256) void optim_vector_kernel(OptArgs a) {
   if (i >= a.rows) return;
   const int64_t idx = a.indexes[i];
   const float w = a.weight[i], tw = a.total_weight[idx];
+  const float gs = a.row_scale ? a.row_scale[i] : 1.0f;
   float norm = 0.0f;
-  for (int j = 0; j < a.dims; ++j) { const float g = a.grad[idx * a.dims + j]; norm += g * g; }
+  for (int j = 0; j < a.dims; ++j) { const float g = a.grad[idx * a.dims + j] * gs; norm += g * g; }
+  float apply = 0.0f;
+  if (a.param) {
+    apply = saturate_weight(w);
+    if (a.point_lr) apply *= a.point_lr[idx];
+  }
   const float v = lerp_pow(a.beta2, w, a.v[idx], norm);
   if (LAPROP) {
     const float bias1 = a.bias_correction ? one_minus_pow(a.beta1, tw) : 1.0f;
     const float bias2 = a.bias_correction ? one_minus_pow(a.beta2, tw) : 1.0f;
     const float denom = fmaxf(sqrtf(v / bias2), a.eps);
     for (int j = 0; j < a.dims; ++j) {
-      const float m = lerp_pow(a.beta1, w, a.m[idx * a.dims + j], a.grad[idx * a.dims + j] / denom);
-      a.lr_step[i * a.dims + j] = m * a.lr / bias1;
+      const float m = lerp_pow(a.beta1, w, a.m[idx * a.dims + j], a.grad[idx * a.dims + j] * gs / denom);
+      const float step = m * a.lr / bias1;
+      if (a.lr_step) a.lr_step[i * a.dims + j] = step;
       a.m[idx * a.dims + j] = m;
+      if (a.param) a.param[idx * a.dims + j] -= step * apply * (a.mask_lr ? a.mask_lr[j] : 1.0f);
     }
   } else {
     const float bias = a.bias_correction ? sqrtf(one_minus_pow(a.beta2, tw)) / (one_minus_pow(a.beta1, tw)) : 1.0f;
     const float denom = fmaxf(sqrtf(v), a.eps);
     for (int j = 0; j < a.dims; ++j) {
-      const float m = lerp_pow(a.beta1, w, a.m[idx * a.dims + j], a.grad[idx * a.dims + j]);
-      a.lr_step[i * a.dims + j] = m / denom * bias * a.lr;
+      const float m = lerp_pow(a.beta1, w, a.m[idx * a.dims + j], a.grad[idx * a.dims + j] * gs);
+      const float step = m / denom * bias * a.lr;
+      if (a.lr_step) a.lr_step[i * a.dims + j] = step;
       a.m[idx * a.dims + j] = m;
+      if (a.param) a.param[idx * a.dims + j] -= step * apply * (a.mask_lr ? a.mask_lr[j] : 1.0f);
     }
   }
   a.v[idx] = v;
@@ -99,12 +124,14 @@ __global__ __launch_bounds__(256) void optim_vector_kernel(OptArgs a) {
 extern "C" int gs_optim_step(int32_t laprop, int32_t vector_group, int64_t rows, int32_t dims, const int64_t* indexes,
                              const float* weight, float* m, float* v, const float* total_weight, const float* grad,
                              float lr, float beta1, float beta2, float eps, int32_t bias_correction, float* lr_step,
+                             const float* row_scale, float* param, const float* mask_lr, const float* point_lr,
                              void* stream) {
   GS_REQUIRE(dims >= 1, GS_ERR_INVALID_ARGUMENT, "gs_optim_step: dims %d", dims);
   if (rows == 0) return GS_OK;
-  GS_REQUIRE(indexes && weight && m && v && total_weight && grad && lr_step, GS_ERR_INVALID_ARGUMENT,
+  GS_REQUIRE(indexes && weight && m && v && total_weight && grad && (lr_step || param), GS_ERR_INVALID_ARGUMENT,
              "gs_optim_step: NULL buffer");
-  OptArgs a{lr_step, indexes, weight, m, v, total_weight, grad, rows, dims, lr, beta1, beta2, eps, bias_correction};
+  OptArgs a{lr_step, indexes, weight, m, v, total_weight, grad, rows, dims, lr, beta1, beta2, eps, bias_correction,
+            row_scale, param, mask_lr, point_lr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (vector_group) {
     const dim3 grid(unsigned(gs_div_up(rows, 256)));

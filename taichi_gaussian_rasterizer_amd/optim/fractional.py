@@ -62,8 +62,12 @@ def get_total_weight(state: dict, n: int, device: torch.device):
 
 
 def weighted_step(group: Group, visible_weight: torch.Tensor, visible_indexes: torch.Tensor,
-                  total_weight: torch.Tensor, kind: int, basis: Optional[torch.Tensor] = None):
-    """reference optim/fractional.py:107-147"""
+                  total_weight: torch.Tensor, kind: int, basis: Optional[torch.Tensor] = None,
+                  row_scale: Optional[torch.Tensor] = None, apply: bool = False):
+    """reference optim/fractional.py:107-147.  With apply=True the kernel also performs the caller's
+    `param[indexes] -= lr_step * saturate(weight)` (with mask_lr / point_lr) for scalar and vector groups and
+    None is returned; local_vector groups need the basis round trip and return lr_step as the reference does.
+    row_scale (one factor per visible row) multiplies the gradient inside the kernel."""
     if group.type in ["vector", "local_vector"]:
         m, v = get_vector_state(group.state, group.param)
         vector = 1
@@ -79,15 +83,28 @@ def weighted_step(group: Group, visible_weight: torch.Tensor, visible_indexes: t
         group.grad[visible_indexes] = torch.einsum('bij,bj->bi', inv_basis, group.grad[visible_indexes])
 
     grad = group.grad.contiguous()
-    nv.require_device(grad, visible_weight, m, v, total_weight, what="optimizer step")
+    nv.require_device(grad, visible_weight, m, v, total_weight, row_scale, what="optimizer step")
     nv.require_device(visible_indexes, dtype=torch.int64, what="optimizer step indexes")
     idx, w = visible_indexes.contiguous(), visible_weight.contiguous()
     rows, dims = idx.shape[0], group.param.shape[1]
-    lr_step = group.param.new_zeros(rows, dims)
+    fused = apply and group.type != "local_vector" and group.param.is_contiguous()
+    mask_lr = point_lr = None
+    if fused:
+        if group.mask_lr is not None:
+            mask_lr = group.mask_lr.reshape(-1).to(dtype=torch.float32).contiguous()
+            assert mask_lr.shape[0] == dims, f"mask_lr has {mask_lr.shape[0]} entries for {dims} columns"
+        if group.point_lr is not None:
+            point_lr = group.point_lr.to(dtype=torch.float32).contiguous()
+        nv.require_device(group.param, mask_lr, point_lr, what="optimizer step")
+    lr_step = None if fused else group.param.new_zeros(rows, dims)
+    scale = None if row_scale is None else row_scale.contiguous()
     nv.check(nv.lib().gs_optim_step(kind, vector, rows, dims, nv.ptr(idx), nv.ptr(w), nv.ptr(m), nv.ptr(v),
                                     nv.ptr(total_weight), nv.ptr(grad), float(group.lr), float(group.betas[0]),
                                     float(group.betas[1]), float(group.eps), int(group.bias_correction),
-                                    nv.ptr(lr_step), nv.stream()), "gs_optim_step")
+                                    nv.ptr(lr_step), nv.ptr(scale), nv.ptr(group.param) if fused else None,
+                                    nv.ptr(mask_lr), nv.ptr(point_lr), nv.stream()), "gs_optim_step")
+    if fused:
+        return None
 
     if group.type == "local_vector":
         lr_step = torch.einsum('bij,bj->bi', basis, lr_step)
@@ -125,8 +142,9 @@ class FractionalOpt(torch.optim.Optimizer):
             if group.grad is None:
                 continue
             assert group.num_points == n, f"param shape {group.num_points} != {n}"
-            lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis)
-            group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
+            lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis, apply=True)
+            if lr_step is not None:
+                group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
 
 
 class FractionalAdam(FractionalOpt):

@@ -62,10 +62,16 @@ class VisibilityOptimizer(torch.optim.Optimizer):
             if group.grad is None:
                 continue
             assert group.num_points == n, f"param shape {group.num_points} != {n}"
-            scaled = group.grad[indexes] * self.grad_scale / (visibility.unsqueeze(1) + self.vis_smooth)
-            group = replace(group, grad=set_indexes(group.grad, scaled, indexes))
-            lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis)
-            group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
+            row_scale = self.grad_scale / (visibility + self.vis_smooth)
+            if group.type == "local_vector":
+                # the basis round trip rewrites the visible gradient rows: work on a copy, as the reference does
+                scaled = group.grad[indexes] * row_scale.unsqueeze(1)
+                group = replace(group, grad=set_indexes(group.grad, scaled, indexes))
+                row_scale = None
+            lr_step = weighted_step(group, weight, indexes, total_weight, self.kind, basis, row_scale=row_scale,
+                                    apply=True)
+            if lr_step is not None:
+                group.param[indexes] -= lr_step * saturate(weight).unsqueeze(1)
 
 
 class VisibilityAwareAdam(VisibilityOptimizer):
