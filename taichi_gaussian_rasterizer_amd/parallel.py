@@ -94,7 +94,8 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
                              world_size: Optional[int] = None, ops: Optional[SimpleNamespace] = None):
     """Render this rank's strip of the frame.  Returns a `Rendering` whose image tensors cover rows
     [y0, y1) of the full image (`rendering.strip == (y0, y1)`); after `.backward()` of a loss summed
-    over strips, every rank holds the full parameter gradients."""
+    over strips, every rank holds the full parameter gradients.  `point_visibility` / `point_heuristic` are this
+    strip's share: `reduce_point_statistics` sums them over the ranks."""
     from .renderer import Rendering, compute_depth_variance
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -154,6 +155,22 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
                   points_in_view=indexes, point_depth=depths, gaussians2d=gaussians2d)
     object.__setattr__(r, "strip", (y0, y1))
     return r
+
+
+def reduce_point_statistics(rendering, group=None):
+    """`point_visibility` / `point_heuristic` of a sharded rendering cover this rank's strip only (they are sums
+    over pixels).  Returns (visibility, heuristic) summed over the ranks -- one small all-reduce of (V,3) floats,
+    to be called after `.backward()` (the heuristic is filled in by the backward pass); None where not computed."""
+    vis, heur = rendering.point_visibility, rendering.point_heuristic
+    parts = [t.reshape(t.shape[0], -1) for t in (vis, heur) if t is not None]
+    if not parts:
+        return None, None
+    packed = torch.cat(parts, dim=1).contiguous()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    out_vis = packed[:, 0].contiguous() if vis is not None else None
+    out_heur = packed[:, (1 if vis is not None else 0):].contiguous() if heur is not None else None
+    return out_vis, out_heur
 
 
 def gather_image(strip_image: torch.Tensor, image_height: int, tile_size: int, group=None) -> torch.Tensor:

@@ -34,7 +34,7 @@ def _run(rank, world, port, size, n, depth_mode, out_dir):
     try:
         g, cam, gi, gdm = _scene(size, n, depth_mode)
         g = g.requires_grad_(True)
-        cfg = RasterConfig()
+        cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
         r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode, ops=oracle_ops.OPS)
         y0, y1 = r.strip
         loss = (r.image * gi[y0:y1]).sum()
@@ -42,7 +42,9 @@ def _run(rank, world, port, size, n, depth_mode, out_dir):
             loss = loss + (r.depth * gdm[y0:y1]).sum()
         loss.backward()
         full = parallel.gather_image(r.image.detach(), size[1], cfg.tile_size)
+        vis, heur = parallel.reduce_point_statistics(r)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=full.numpy(), strip=np.array([y0, y1]),
+                 vis=vis.numpy(), heur=heur.numpy(),
                  **{f"d_{k}": v.grad.numpy() for k, v in g.items()})
     finally:
         dist.destroy_process_group()
@@ -55,7 +57,7 @@ def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_m
 
     g, cam, gi, gdm = _scene(size, n, depth_mode)
     g = g.requires_grad_(True)
-    cfg = RasterConfig()
+    cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
     r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode, ops=oracle_ops.OPS,
                                           rank=0, world_size=1)
     loss = (r.image * gi).sum()
@@ -68,6 +70,9 @@ def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_m
         covered.append(tuple(z["strip"]))
         # strips are rendered by the same arithmetic on exactly shifted coordinates
         assert np.allclose(z["image"], r.image.detach().numpy(), rtol=0, atol=1e-6)
+        # per-strip visibility / heuristics summed over the ranks = the single-process statistics
+        assert np.allclose(z["vis"], r.point_visibility.numpy(), rtol=1e-4, atol=1e-5)
+        assert np.allclose(z["heur"], r.point_heuristic.numpy(), rtol=1e-3, atol=1e-4 * max(1.0, float(r.point_heuristic.abs().max())))
         for k, v in g.items():
             ref = v.grad.numpy()
             assert np.allclose(z[f"d_{k}"], ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max())), (rank, k)
