@@ -202,19 +202,29 @@ class _FusedRender(torch.autograd.Function):
             else:
                 extra_depth = g_depth.contiguous()
 
+        g_feat, g_feat_stride = _off(rows, 7 + col0), RS     # dL/d(SH colour) columns
+        g_pts, g_pts_stride = rows, RS                        # dL/d(points) [+ depth feature] columns
+        wait_points = None
         if m["sharded"]:
-            # every rank rendered a different strip: sum the per-Gaussian partial gradients with ONE
-            # all-reduce of the used columns (4*(7+F) bytes per visible Gaussian), then continue replicated
+            # Every rank rendered a different strip: the per-Gaussian partial gradients are summed over the
+            # ranks, 4*(7+F) bytes per visible Gaussian in all.  Two collectives, colour columns first: the SH
+            # adjoint only needs those and runs while the splat columns are still in flight.
             import torch.distributed as dist
-            packed = rows[:, :7 + F].contiguous()
+            pf = rows[:, 7 + col0:7 + F].contiguous()
+            pp = rows[:, :7 + col0].contiguous()
             if dist.is_available() and dist.is_initialized() and dist.get_world_size(m["group"]) > 1:
-                dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=m["group"])
-            rows, RS = packed, 7 + F
+                wf = dist.all_reduce(pf, op=dist.ReduceOp.SUM, group=m["group"], async_op=True)
+                wait_points = dist.all_reduce(pp, op=dist.ReduceOp.SUM, group=m["group"], async_op=True)
+                wf.wait()
+            g_feat, g_feat_stride = nv.ptr(pf), C
+            g_pts, g_pts_stride = pp, 7 + col0
 
         d_feature = torch.empty_like(feature)
         nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
-                               nv.ptr(slot_of), nv.ptr(cam_pos), _off(rows, 7 + col0), RS, _off(feats, col0), F,
+                               nv.ptr(slot_of), nv.ptr(cam_pos), g_feat, g_feat_stride, _off(feats, col0), F,
                                nv.ptr(d_feature), None, None, s), "gs_sh_bwd")
+        if wait_points is not None:
+            wait_points.wait()
 
         need_T, need_proj = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
         d_pos, d_ls = torch.empty_like(position), torch.empty_like(log_scaling)
@@ -224,14 +234,14 @@ class _FusedRender(torch.autograd.Function):
         nbytes = lib.gs_project_bwd_scratch_bytes(n) if (need_T or need_proj) else 0
         scratch = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         if m["render_depth"]:
-            gd, gd2, gstride = _off(rows, 7), _off(rows, 8), RS
+            gd, gd2, gstride = _off(g_pts, 7), _off(g_pts, 8), g_pts_stride
         else:
             gd, gd2, gstride = nv.ptr(extra_depth), None, 1
         nv.check(lib.gs_project_bwd(n, V, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
-                                    nv.ptr(T), nv.ptr(proj), w, m["full_h"], cfg, nv.ptr(slot_of), nv.ptr(rows), RS, gd,
-                                    gd2,
-                                    gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot), nv.ptr(d_al), nv.ptr(d_T),
-                                    nv.ptr(d_proj), nv.ptr(scratch), nbytes, s), "gs_project_bwd")
+                                    nv.ptr(T), nv.ptr(proj), w, m["full_h"], cfg, nv.ptr(slot_of), nv.ptr(g_pts),
+                                    g_pts_stride, gd, gd2, gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot),
+                                    nv.ptr(d_al), nv.ptr(d_T), nv.ptr(d_proj), nv.ptr(scratch), nbytes, s),
+                 "gs_project_bwd")
         return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None
 
 
