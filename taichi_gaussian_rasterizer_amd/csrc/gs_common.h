@@ -43,7 +43,7 @@ static inline int gs_check_cfg(const GsRasterConfig* cfg) {
 // tile grid alone fills the chip (256 CUs x 4 SIMDs x ~8 waves); 2 or 1 for small grids (training-size
 // images, a tile-row strip of a sharded frame), which then run 2x / 4x as many waves at some extra
 // staging work per splat.  GS_RASTER_NB=1|2|4 overrides (tuning aid).  Results do not depend on it.
-int gs_raster_sub_blocks(int tile_size, int64_t num_tiles);
+int gs_raster_sub_blocks(int tile_size, int64_t num_tiles, int backward);
 
 // ------------------------------------------------------------------ device helpers
 #ifdef __HIPCC__

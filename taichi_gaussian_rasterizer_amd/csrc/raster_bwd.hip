@@ -391,7 +391,7 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.tiles_wide = int(gs_div_up(width, ts));
   a.tile_size = ts;
   const int num_tiles = a.tiles_wide * int(gs_div_up(height, ts));
-  const int nb = gs_raster_sub_blocks(ts, num_tiles);
+  const int nb = gs_raster_sub_blocks(ts, num_tiles, 1);
   a.sub_x = ts / (nb == 1 ? 8 : 16);
   a.sub_y = ts / (nb == 4 ? 16 : 8);
   a.num_items = num_tiles * a.sub_x * a.sub_y;
