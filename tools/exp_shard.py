@@ -16,7 +16,7 @@ for world in (1, 2, 4, 8):
         for _, t in gg.items(): t.grad = None
         r = parallel.render_gaussians_sharded(gg, cam, cfg, use_sh=True, rank=rank, world_size=world)
         y0, y1 = r.strip
-        (r.image * G[y0:y1]).sum().backward()
+        r.image.backward(G[y0:y1])
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
