@@ -11,7 +11,7 @@ gg = g.to('cuda:0').requires_grad_(True)
 def step():
     for _, t in gg.items(): t.grad = None
     r = gs.render_gaussians(gg, cam, cfg, use_sh=True)
-    (r.image * G).sum().backward()
+    r.image.backward(G)
 for _ in range(20): step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(200): step()
