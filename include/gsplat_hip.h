@@ -194,12 +194,14 @@ int gs_find_ranges(int64_t k, const uint64_t* sorted_keys, int32_t use_depth16, 
  * T = ceil(W/ts)*ceil(H/ts), overlap_to_point (K) int32.  image (H,W,F), alpha (H,W).
  * visibility (V) must be zero-filled by the caller when cfg->compute_visibility, else may be NULL.
  * tile_order (optional, T int32, a permutation of the tile ids, from gs_map_prepare): launch order;
- * NULL = XCD-contiguous bands.  Results do not depend on it.
+ * NULL = XCD-contiguous bands.  heavy_tiles (optional, device int32, from gs_map_prepare's counts_out[3]): the
+ * first *heavy_tiles tiles of the order are rasterized by four workgroups each (one per 8x8 quadrant; tile_size
+ * 16 only, ignored otherwise) so that no single wave walks a very full tile alone.  Results depend on neither.
  */
 int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
                   const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                  int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, float* image, float* alpha,
-                  float* visibility, void* stream);
+                  int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const int32_t* heavy_tiles,
+                  float* image, float* alpha, float* visibility, void* stream);
 
 /* replaces: rasterizer/backward.py:53-228 _backward_kernel.
  * Per-Gaussian gradients are accumulated with float atomics into ONE row per Gaussian,
@@ -212,8 +214,8 @@ int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const fl
 int32_t gs_grad_row_floats(int32_t num_features);
 int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
                   const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                  int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const float* image,
-                  const float* grad_image, float* grad_rows, void* stream);
+                  int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const int32_t* heavy_tiles,
+                  const float* image, const float* grad_image, float* grad_rows, void* stream);
 int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
                          float* grad_features, float* point_heuristic, void* stream);
 

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
     counts_out[0] = carry;
     counts_out[1] = m;
     counts_out[2] = (k_capacity > 0 && int64_t(carry) > k_capacity) ? 1 : 0;
-    counts_out[3] = 0;
+    if (!tile_order) counts_out[3] = 0;
   }
   if (!tile_order) return;
   __syncthreads();
@@ -199,6 +199,14 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   int unused;
   const int start = block_exclusive_scan(s_bin[1023 - t], s_wave, unused);
   s_bin[1023 - t] = start;  // read above and written here by the same thread only
+  // counts_out[3] = number of "heavy" tiles at the head of the order, which the rasterizer splits into four
+  // 8x8 workgroups each.  A launch cannot end before ONE wave has walked its fullest tile (n splats take about
+  // 1.75 n c when the wave has a SIMD to itself), while the whole launch takes about K c / 1024 on 1024 SIMDs:
+  // tiles with n > K / 1792 are the ones that bound it.  Large grids (K / 1792 above every tile) split nothing.
+  {
+    const int thr_bin = min(max(carry / 1792, 96), 1022);
+    if (1023 - t == thr_bin) counts_out[3] = min(start, num_tiles / 4);  // tiles in bins above thr_bin
+  }
   __syncthreads();
   for (int i = t; i < num_tiles; i += 1024) tile_order[atomicAdd(&s_bin[min(tile_hist[i], 1023)], 1)] = i;
 }

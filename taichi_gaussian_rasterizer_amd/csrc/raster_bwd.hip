@@ -40,6 +40,9 @@ struct BwdArgs {
   int tile_size;
   int sub_x, sub_y;  // wave regions per tile along x / y
   int num_items;
+  int num_tiles;
+  const int* heavy;  // optional (device): the first *heavy entries of tile_order get four 8x8 workgroups each
+  int heavy_cap;
   const int* tile_order;  // optional launch order of the items (heaviest first)
   float cmax, thr, sat;
   int aa, heur;
@@ -58,26 +61,21 @@ __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, f
 #define GS_BWD_WAVES 1  // minimum waves per SIMD requested from the register allocator (1 = no constraint)
 #endif
 
-template <int NB, int FP, bool FULL>
-__global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
-  // launch order: heaviest tiles first when the mapper supplied an order (shortens the tail of the
-  // launch: a tile's cost is proportional to its splat count), else XCD-contiguous bands
-  const int per_tile = a.sub_x * a.sub_y;
-  int item;
-  if (a.tile_order) {
-    if (int(blockIdx.x) >= a.num_items) return;
-    item = a.tile_order[blockIdx.x / per_tile] * per_tile + blockIdx.x % per_tile;
-  } else {
-    item = gs_xcd_remap(blockIdx.x, a.num_items);
-    if (item < 0) return;
-  }
-  const int lane = threadIdx.x;
-  const int tile = item / per_tile, quad = item - tile * per_tile;
-  constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
-  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
-  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
-  if (x0 >= a.W || y0 >= a.H) return;
+// LDS arena of one wave: sized by the 64-splat staging group, not by the wave's pixel region
+template <int FP, bool FULL>
+struct BwdShape {
+  static constexpr int NS = FULL ? 9 : 6;        // lean: 6 moment sums; full: 7 gradients + 2 heuristics
+  static constexpr int NACC = NS + FP;           // values reduced per splat
+  static constexpr int ROW = ((9 + FP + 15) / 16) * 16;
+  static constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
+  static constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
+  static constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
+  static constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
+};
 
+template <int NB, int FP, bool FULL>
+__device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, float* smem, int* s_idx) {
+  const int lane = threadIdx.x;
   constexpr int NS = FULL ? 9 : 6;        // lean: 6 moment sums; full: 7 gradients + 2 heuristics
   constexpr int NACC = NS + FP;           // values reduced per splat
   constexpr int ROW = ((9 + FP + 15) / 16) * 16;
@@ -89,8 +87,6 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
   constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
   constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
-  __shared__ __attribute__((aligned(16))) float smem[ARENA_F];
-  __shared__ int s_idx[64];
   float4(*s_geo)[GEO_V4] = reinterpret_cast<float4(*)[GEO_V4]>(smem);
   float(*s_feat)[FP] = reinterpret_cast<float(*)[FP]>(smem + GEO_F);
   float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + GEO_F + FEAT_F);
@@ -341,9 +337,42 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   }
 }
 
+// Block -> work: see raster_fwd_kernel (the mapper's fullest tiles get one workgroup per 8x8 quadrant).
+template <int NB, int FP, bool FULL>
+__global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
+  __shared__ __attribute__((aligned(16))) float smem[BwdShape<FP, FULL>::ARENA_F];
+  __shared__ int s_idx[64];
+  const int per_tile = a.sub_x * a.sub_y;
+  constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
+  int tile, quad;
+  if (a.tile_order) {
+    const int b = blockIdx.x;
+    const int heavy = (NB > 1 && a.heavy) ? min(*a.heavy, a.heavy_cap) : 0;
+    if (NB > 1 && b < 4 * heavy) {
+      tile = a.tile_order[b >> 2];
+      const int x0 = (tile % a.tiles_wide) * 16 + (b & 1) * 8, y0 = (tile / a.tiles_wide) * 16 + ((b >> 1) & 1) * 8;
+      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, FULL>(a, tile, x0, y0, smem, s_idx);
+      return;
+    }
+    const int c = b - 4 * heavy, rank = heavy + c / per_tile;
+    if (rank >= a.num_tiles) return;
+    tile = a.tile_order[rank];
+    quad = c % per_tile;
+  } else {
+    const int item = gs_xcd_remap(blockIdx.x, a.num_items);
+    if (item < 0) return;
+    tile = item / per_tile;
+    quad = item - tile * per_tile;
+  }
+  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
+  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
+  if (x0 >= a.W || y0 >= a.H) return;
+  raster_bwd_body<NB, FP, FULL>(a, tile, x0, y0, smem, s_idx);
+}
+
 template <int NB, bool FULL>
 int launch_fp(const BwdArgs& a, hipStream_t s) {
-  const int grid = 8 * int(gs_div_up(a.num_items, 8));
+  const int grid = 8 * int(gs_div_up(a.num_items + (a.heavy ? 4 * a.heavy_cap : 0), 8));
   if (a.F <= 3) hipLaunchKernelGGL((raster_bwd_kernel<NB, 3, FULL>), dim3(grid), dim3(64), 0, s, a);
   else if (a.F <= 5) hipLaunchKernelGGL((raster_bwd_kernel<NB, 5, FULL>), dim3(grid), dim3(64), 0, s, a);
   else if (a.F <= 8) hipLaunchKernelGGL((raster_bwd_kernel<NB, 8, FULL>), dim3(grid), dim3(64), 0, s, a);
@@ -370,8 +399,9 @@ extern "C" int32_t gs_grad_row_floats(int32_t num_features) { return int32_t(gs_
 
 extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
                              const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                             int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const float* image,
-                             const float* grad_image, float* grad_rows, void* stream) {
+                             int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order,
+                             const int32_t* heavy_tiles, const float* image, const float* grad_image,
+                             float* grad_rows, void* stream) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_bwd: image size %dx%d", width, height);
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
@@ -396,6 +426,9 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.sub_y = ts / (nb == 4 ? 16 : 8);
   a.num_items = num_tiles * a.sub_x * a.sub_y;
   a.tile_order = tile_order;
+  a.num_tiles = num_tiles;
+  a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
+  a.heavy_cap = num_tiles / 4;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -39,6 +39,9 @@ struct FwdArgs {
   int tile_size;
   int sub_x, sub_y;  // wave regions per tile along x / y
   int num_items;
+  int num_tiles;
+  const int* heavy;  // optional (device): the first *heavy entries of tile_order get four 8x8 workgroups each
+  int heavy_cap;
   const int* tile_order;  // optional launch order of the items (heaviest first)  // tiles * sub * sub
   float cmax, thr, sat_level;
   int blend, vis, aa;
@@ -53,30 +56,10 @@ __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
 // NB: 8x8 sub-blocks per wave (1, 2 or 4; gs_raster_sub_blocks picks it from the grid size).  FP: padded feature width.  FULL: runtime switches for
 // quantile mode / visibility / antialias (the common blend-only case gets its own lean kernel).
 template <int NB, int FP, bool FULL>
-__global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
-  // launch order: heaviest tiles first when the mapper supplied an order (shortens the tail of the
-  // launch: a tile's cost is proportional to its splat count), else XCD-contiguous bands
-  const int per_tile = a.sub_x * a.sub_y;
-  int item;
-  if (a.tile_order) {
-    if (int(blockIdx.x) >= a.num_items) return;
-    item = a.tile_order[blockIdx.x / per_tile] * per_tile + blockIdx.x % per_tile;
-  } else {
-    item = gs_xcd_remap(blockIdx.x, a.num_items);
-    if (item < 0) return;
-  }
+__device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0,
+                                                float4 (*s_geo)[FULL ? 3 : 2], float (*s_feat)[FP], float* s_vis,
+                                                int* s_idx) {
   const int lane = threadIdx.x;
-  const int tile = item / per_tile, quad = item - tile * per_tile;
-  constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
-  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
-  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
-  if (x0 >= a.W || y0 >= a.H) return;
-
-  __shared__ float4 s_geo[64][FULL ? 3 : 2];
-  __shared__ float s_feat[64][FP];
-  __shared__ float s_vis[FULL ? 64 : 1];
-  __shared__ int s_idx[FULL ? 64 : 1];
-
   const int lx = lane & 7, ly = lane >> 3;
   float Xf[NB], Yf[NB], Wt[NB], acc[NB][FP];
   bool inb[NB], done[NB];
@@ -220,9 +203,47 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
   }
 }
 
+// Block -> work.  With a launch order from the mapper: its first `*heavy` tiles (the fullest ones; tile_size 16
+// only) are rasterized by FOUR workgroups each, one per 8x8 quadrant, the others by workgroups of the grid's
+// own wave region -- a launch cannot end before its fullest tile has been walked by one wave, which is what
+// bounds small grids (strips of a sharded frame, training-size images).  Without an order: XCD-contiguous bands.
+template <int NB, int FP, bool FULL>
+__global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
+  __shared__ float4 s_geo[64][FULL ? 3 : 2];
+  __shared__ float s_feat[64][FP];
+  __shared__ float s_vis[FULL ? 64 : 1];
+  __shared__ int s_idx[FULL ? 64 : 1];
+  const int per_tile = a.sub_x * a.sub_y;
+  constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
+  int tile, quad;
+  if (a.tile_order) {
+    const int b = blockIdx.x;
+    const int heavy = (NB > 1 && a.heavy) ? min(*a.heavy, a.heavy_cap) : 0;
+    if (NB > 1 && b < 4 * heavy) {
+      tile = a.tile_order[b >> 2];
+      const int x0 = (tile % a.tiles_wide) * 16 + (b & 1) * 8, y0 = (tile / a.tiles_wide) * 16 + ((b >> 1) & 1) * 8;
+      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, FULL>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
+      return;
+    }
+    const int c = b - 4 * heavy, rank = heavy + c / per_tile;
+    if (rank >= a.num_tiles) return;
+    tile = a.tile_order[rank];
+    quad = c % per_tile;
+  } else {
+    const int item = gs_xcd_remap(blockIdx.x, a.num_items);
+    if (item < 0) return;
+    tile = item / per_tile;
+    quad = item - tile * per_tile;
+  }
+  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
+  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
+  if (x0 >= a.W || y0 >= a.H) return;
+  raster_fwd_body<NB, FP, FULL>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
+}
+
 template <int NB, bool FULL>
 int launch_fp(const FwdArgs& a, hipStream_t s) {
-  const int grid = 8 * int(gs_div_up(a.num_items, 8));
+  const int grid = 8 * int(gs_div_up(a.num_items + (a.heavy ? 4 * a.heavy_cap : 0), 8));
   if (a.F <= 3) hipLaunchKernelGGL((raster_fwd_kernel<NB, 3, FULL>), dim3(grid), dim3(64), 0, s, a);
   else if (a.F <= 5) hipLaunchKernelGGL((raster_fwd_kernel<NB, 5, FULL>), dim3(grid), dim3(64), 0, s, a);
   else if (a.F <= 8) hipLaunchKernelGGL((raster_fwd_kernel<NB, 8, FULL>), dim3(grid), dim3(64), 0, s, a);
@@ -235,8 +256,8 @@ int launch_fp(const FwdArgs& a, hipStream_t s) {
 
 extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
                              const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
-                             int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, float* image,
-                             float* alpha, float* visibility, void* stream) {
+                             int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order,
+                             const int32_t* heavy_tiles, float* image, float* alpha, float* visibility, void* stream) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_fwd: image size %dx%d", width, height);
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
@@ -259,6 +280,10 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   a.sub_y = ts / (nb == 4 ? 16 : 8);
   a.num_items = num_tiles * a.sub_x * a.sub_y;
   a.tile_order = tile_order;
+  a.num_tiles = num_tiles;
+  // the split needs the 2x2-quadrant geometry of a 16-pixel tile and a launch order to index into
+  a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
+  a.heavy_cap = num_tiles / 4;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;

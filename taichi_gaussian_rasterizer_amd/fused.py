@@ -74,7 +74,7 @@ class _FusedRender(torch.autograd.Function):
         feats = torch.empty((n, F), **f32)
         indexes = torch.empty((n,), dtype=torch.int64, device=dev)
         slot_of = torch.empty((n,), dtype=torch.int32, device=dev)
-        counts = torch.zeros((8,), dtype=torch.int32, device=dev)  # [0] = V ; [4:8] = K, fullest tile, overflow, -
+        counts = torch.zeros((8,), dtype=torch.int32, device=dev)  # [0] = V ; [4:8] = K, fullest tile, overflow, heavy tiles
         cam_pos = torch.empty((3,), **f32)
         pbytes = lib.gs_project_scratch_bytes(n)
         pscratch = torch.empty((max(pbytes, 1),), dtype=torch.uint8, device=dev)
@@ -121,7 +121,8 @@ class _FusedRender(torch.autograd.Function):
             alpha = torch.empty((h, w), **f32)
             vis = torch.zeros((n,), **f32) if want_vis else None
             nv.check(lib.gs_raster_fwd(n, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), k_cap,
-                                       w, h, cfg, nv.ptr(tile_order), nv.ptr(image), nv.ptr(alpha), nv.ptr(vis), s),
+                                       w, h, cfg, nv.ptr(tile_order), _off(counts, 7), nv.ptr(image), nv.ptr(alpha),
+                                       nv.ptr(vis), s),
                      "gs_raster_fwd")
             return o2p, image, alpha, vis
 
@@ -156,7 +157,7 @@ class _FusedRender(torch.autograd.Function):
         # outputs nobody differentiates through (projected splats, depths) must not cost zero-filled gradients
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
-                              indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth, tile_order)
+                              indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth, tile_order, counts)
         ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur)
         if not render_depth:
             ctx.mark_non_differentiable(img_depth, img_var)
@@ -165,7 +166,7 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var):
         (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
-         tile_ranges, o2p, image, alpha, img_depth, tile_order) = ctx.saved_tensors
+         tile_ranges, o2p, image, alpha, img_depth, tile_order, counts) = ctx.saved_tensors
         m = ctx.meta
         lib = nv.lib()
         dev = position.device
@@ -188,7 +189,8 @@ class _FusedRender(torch.autograd.Function):
             gi = g_image.contiguous()
             nv.require_device(gi, what="render_gaussians backward")
             nv.check(lib.gs_raster_bwd(V, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), K, w, h,
-                                       cfg, nv.ptr(tile_order), nv.ptr(image), nv.ptr(gi), nv.ptr(rows), s),
+                                       cfg, nv.ptr(tile_order), _off(counts, 7), nv.ptr(image), nv.ptr(gi),
+                                       nv.ptr(rows), s),
                      "gs_raster_bwd")
         if config.compute_point_heuristic and V > 0:
             ctx.heur.copy_(rows[:V, 7 + F:9 + F])

@@ -43,7 +43,7 @@ class _RasterFunction(torch.autograd.Function):
         vis = (torch.zeros((v,), dtype=torch.float32, device=dev) if want_vis
                else torch.empty((0,), dtype=torch.float32, device=dev))
         nv.check(lib.gs_raster_fwd(v, F, nv.ptr(g), nv.ptr(f), nv.ptr(ranges), nv.ptr(o2p), o2p.shape[0], w, h,
-                                   nv.make_config(config), None, nv.ptr(image), nv.ptr(alpha),
+                                   nv.make_config(config), None, None, nv.ptr(image), nv.ptr(alpha),
                                    nv.ptr(vis) if want_vis else None, nv.stream()), "gs_raster_fwd")
         if not config.compute_visibility:
             vis_out = torch.empty((0,), dtype=torch.float32, device=dev) if not want_vis else vis
@@ -67,7 +67,7 @@ class _RasterFunction(torch.autograd.Function):
         row = lib.gs_grad_row_floats(F)
         rows = torch.zeros((v, row), dtype=torch.float32, device=g.device)
         nv.check(lib.gs_raster_bwd(v, F, nv.ptr(g), nv.ptr(f), nv.ptr(ranges), nv.ptr(o2p), o2p.shape[0], w, h,
-                                   nv.make_config(config), None, nv.ptr(image), nv.ptr(gi), nv.ptr(rows),
+                                   nv.make_config(config), None, None, nv.ptr(image), nv.ptr(gi), nv.ptr(rows),
                                    nv.stream()), "gs_raster_bwd")
         grad_g = torch.empty_like(g)
         grad_f = torch.empty_like(f)

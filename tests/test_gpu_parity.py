@@ -598,6 +598,32 @@ def test_fused_frame_gradients_through_projected_splats(depth_mode):
     assert a.feature.grad is None or float(a.feature.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("nb", ["2", "4"])
+def test_fused_frame_splits_heavy_tiles(nb, monkeypatch):
+    """the mapper marks the fullest tiles of its launch order (counts_out[3]) and the rasterizer gives each of them
+    four 8x8 workgroups; with 16x16 / 16x8 wave regions forced on a small, crowded frame a quarter of the tiles take
+    that path: pixels must be identical to the unsplit rasterizer, gradients equal up to summation order"""
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    size, n = (256, 192), 12000
+    cfg = RasterConfig()
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=1, seed=21)
+    cam = camera.to(device=DEV)
+    gi = dev(torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(3)))
+    b = g.to(DEV).requires_grad_(True)            # composed operators: no launch order, nothing is split
+    g2d, depths, idx, ndc = hip_proj.project_with_ndc(*b.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                      cam.image_size, cam.depth_range, cfg)
+    feats = gs.evaluate_sh_at(b.feature, b.position.detach(), idx, cam.camera_position)
+    r2 = render_projected(idx, g2d, feats, depths, cam, cfg, render_depth=False, ndc_depths=ndc)
+    (r2.image * gi).sum().backward()
+    monkeypatch.setenv("GS_RASTER_NB", nb)
+    a = g.to(DEV).requires_grad_(True)
+    r = gs.render_gaussians(a, cam, cfg, use_sh=True)
+    (r.image * gi).sum().backward()
+    assert torch.equal(r.image, r2.image) and torch.equal(r.image_weight, r2.image_weight)
+    for k, t in a.items():
+        pu.assert_grad_close(t.grad, getattr(b, k).grad, f"grad {k} with split tiles", tol=1e-3)
+
+
 def test_fused_frame_capacity_overflow_rerun():
     from taichi_gaussian_rasterizer_amd import fused
     size, n = (256, 192), 8000
