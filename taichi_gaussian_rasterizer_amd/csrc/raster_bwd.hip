@@ -22,6 +22,8 @@
 //
 // Roofline: algorithmic HBM bytes 8T + K(4+28+4F) + 8PF + 4(7+F)K; VALU-bound.
 
+#include <stdlib.h>
+
 #include "gs_common.h"
 
 namespace {
@@ -429,6 +431,9 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.num_tiles = num_tiles;
   a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
   a.heavy_cap = num_tiles / 4;
+  if (const char* e = getenv("GS_RASTER_HEAVY")) {  // tuning aid: 0 = never split
+    if (e[0] == '0') a.heavy = nullptr;
+  }
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);

@@ -22,6 +22,8 @@
 // Roofline: algorithmic HBM bytes K*(4 + 28 + 4F) + 16T + 4P(F+1); the kernel is
 // VALU-bound (about 20 VALU + 1 v_exp_f32 per evaluated pixel-splat pair).
 
+#include <stdlib.h>
+
 #include "gs_common.h"
 
 namespace {
@@ -284,6 +286,9 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   // the split needs the 2x2-quadrant geometry of a 16-pixel tile and a launch order to index into
   a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
   a.heavy_cap = num_tiles / 4;
+  if (const char* e = getenv("GS_RASTER_HEAVY")) {  // tuning aid: 0 = never split
+    if (e[0] == '0') a.heavy = nullptr;
+  }
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;

@@ -48,10 +48,11 @@ def test_mapper_bit_exact(seed, n, size, tile, depth16):
         assert (pu.to_np(keys).view(np.uint64) == keys_ref).all(), f"{fn.__name__}: sort keys differ"
 
 
-def test_mapper_crowded_tile_uses_global_bitonic():
-    """more splats on one tile than the LDS sort holds (8192): in-place global-memory bitonic path"""
+@pytest.mark.parametrize("n", [600, 1500, 4000, 9000])
+def test_mapper_crowded_tile(n):
+    """one tile holding more splats than the wave rank sort covers (512): workgroup merge sort in LDS up to 4096,
+    in-place global-memory bitonic network beyond"""
     torch.manual_seed(0)
-    n = 9000
     g2d = torch.cat([torch.rand(n, 2) * 14 + 1, torch.tensor([[1.0, 0.0]]).expand(n, 2), torch.rand(n, 2) + 0.5,
                      torch.rand(n, 1) * 0.5 + 0.3], 1).float()
     depth = torch.rand(n, 1)
