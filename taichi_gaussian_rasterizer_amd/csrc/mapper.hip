@@ -223,6 +223,7 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
 constexpr int RG_MIN = 8;              // smallest region edge in tiles
 constexpr int RB = 4;                  // window border in tiles (splats reaching further fall back to global atomics)
 constexpr int MAX_REGIONS = 1024;
+constexpr int WIDE_SPAN = 64;          // candidate tiles above which a splat is walked by its whole wave
 #ifndef GS_MAP_CHUNK
 #define GS_MAP_CHUNK 512
 #endif
@@ -369,17 +370,33 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
   for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) s_win[e] = 0;
   __syncthreads();
   const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
+  auto add_tile = [&](int gx, int gy) {
+    const int lx = gx - wx0, ly = gy - wy0;
+    if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_win[ly * WIN + lx], 1);
+    else atomicAdd(tile_hist + gx + gy * a.tiles_wide, 1);
+  };
+  int i = 0;
+  bool wide = false;
   if (int(threadIdx.x) < count) {
-    const int i = order[first + threadIdx.x];
+    i = order[first + threadIdx.x];
     const GridQuery q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
-    for (int ty = 0; ty < q.span_y; ++ty)
-      for (int tx = 0; tx < q.span_x; ++tx)
-        if (test_tile(q, tx, ty, a.tile_size)) {
-          const int gx = tx + q.min_tx, gy = ty + q.min_ty;
-          const int lx = gx - wx0, ly = gy - wy0;
-          if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_win[ly * WIN + lx], 1);
-          else atomicAdd(tile_hist + gx + gy * a.tiles_wide, 1);
-        }
+    wide = q.span_x * q.span_y > WIDE_SPAN;
+    if (!wide)
+      for (int ty = 0; ty < q.span_y; ++ty)
+        for (int tx = 0; tx < q.span_x; ++tx)
+          if (test_tile(q, tx, ty, a.tile_size)) add_tile(tx + q.min_tx, ty + q.min_ty);
+  }
+  // Splats with a wide candidate span (hundreds of tiles for a floater that covers the screen) are walked by
+  // the whole wave, 64 tiles per step: one lane looping over them alone would hold its workgroup for
+  // milliseconds (a dependent global atomic per tile).
+  for (uint64_t todo = __ballot(wide); todo != 0ull; todo &= todo - 1ull) {
+    const int gi = __shfl(i, __ffsll(static_cast<unsigned long long>(todo)) - 1);
+    const GridQuery q = grid_query(a.points + 7 * int64_t(gi), a.Wp, a.Hp, a.tile_size, a.thr);
+    const int total = q.span_x * q.span_y;
+    for (int k = int(threadIdx.x & 63); k < total; k += 64) {
+      const int ty = k / q.span_x, tx = k - ty * q.span_x;
+      if (test_tile(q, tx, ty, a.tile_size)) add_tile(tx + q.min_tx, ty + q.min_ty);
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) {
@@ -394,7 +411,7 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
 // K6: bucket the (depth key, index) pairs.  Pass A counts into the LDS window, pass B reserves one
 // contiguous range per window tile with a single returning global atomic, pass C places the pairs
 // with LDS atomics.  The accepted-tile set of a lane is kept as a 64-bit mask between the passes
-// when its candidate span fits (<= 64 tiles), so the OBB tests run once.
+// (so the OBB tests run once); splats whose candidate span exceeds 64 tiles are walked by the whole wave.
 __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                           const int* region_start, const int* chunk_start,
                                                           int* cursors, uint64_t* pairs) {
@@ -408,23 +425,38 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
   __syncthreads();
   const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
   const bool active = int(threadIdx.x) < count;
+  const int lane = int(threadIdx.x & 63);
   GridQuery q;
   q.span_x = q.span_y = 0;
   uint64_t accept = 0ull;
-  bool masked = false;
+  bool wide = false;  // candidate span above WIDE_SPAN tiles: walked by the whole wave in both passes
   int i = 0;
   if (active) {
     i = order[first + threadIdx.x];
     q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
-    masked = q.span_x * q.span_y <= 64;
-    int bit = 0;
-    for (int ty = 0; ty < q.span_y; ++ty)
-      for (int tx = 0; tx < q.span_x; ++tx, ++bit)
-        if (test_tile(q, tx, ty, a.tile_size)) {
-          if (masked) accept |= 1ull << bit;
-          const int lx = tx + q.min_tx - wx0, ly = ty + q.min_ty - wy0;
-          if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
-        }
+    wide = q.span_x * q.span_y > WIDE_SPAN;
+    if (!wide) {
+      int bit = 0;
+      for (int ty = 0; ty < q.span_y; ++ty)
+        for (int tx = 0; tx < q.span_x; ++tx, ++bit)
+          if (test_tile(q, tx, ty, a.tile_size)) {
+            accept |= 1ull << bit;
+            const int lx = tx + q.min_tx - wx0, ly = ty + q.min_ty - wy0;
+            if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
+          }
+    }
+  }
+  const uint64_t wide_lanes = __ballot(wide);
+  for (uint64_t todo = wide_lanes; todo != 0ull; todo &= todo - 1ull) {
+    const int gi = __shfl(i, __ffsll(static_cast<unsigned long long>(todo)) - 1);
+    const GridQuery w = grid_query(a.points + 7 * int64_t(gi), a.Wp, a.Hp, a.tile_size, a.thr);
+    const int total = w.span_x * w.span_y;
+    for (int k = lane; k < total; k += 64) {
+      const int ty = k / w.span_x, tx = k - ty * w.span_x;
+      if (!test_tile(w, tx, ty, a.tile_size)) continue;
+      const int lx = tx + w.min_tx - wx0, ly = ty + w.min_ty - wy0;
+      if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
+    }
   }
   __syncthreads();
   for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) {
@@ -439,26 +471,35 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
     s_cnt[e] = 0;
   }
   __syncthreads();
-  if (active) {
+  auto place = [&](int gx, int gy, uint64_t pair) {
+    const int lx = gx - wx0, ly = gy - wy0;
+    int slot;
+    if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) {
+      const int e = ly * WIN + lx;
+      if (s_base[e] < 0) return;
+      slot = s_base[e] + atomicAdd(&s_cnt[e], 1);
+    } else {
+      slot = atomicAdd(cursors + gx + gy * a.tiles_wide, 1);
+      if (slot < 0) return;
+    }
+    pairs[slot] = pair;
+  };
+  if (active && !wide) {
     const uint64_t pair = (uint64_t(depth_key(a.depth[i], a.depth16 != 0)) << 32) | uint64_t(uint32_t(i));
     int bit = 0;
     for (int ty = 0; ty < q.span_y; ++ty)
-      for (int tx = 0; tx < q.span_x; ++tx, ++bit) {
-        const bool hit = masked ? ((accept >> bit) & 1ull) != 0ull : test_tile(q, tx, ty, a.tile_size);
-        if (!hit) continue;
-        const int gx = tx + q.min_tx, gy = ty + q.min_ty;
-        const int lx = gx - wx0, ly = gy - wy0;
-        int slot;
-        if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) {
-          const int e = ly * WIN + lx;
-          if (s_base[e] < 0) continue;
-          slot = s_base[e] + atomicAdd(&s_cnt[e], 1);
-        } else {
-          slot = atomicAdd(cursors + gx + gy * a.tiles_wide, 1);
-          if (slot < 0) continue;
-        }
-        pairs[slot] = pair;
-      }
+      for (int tx = 0; tx < q.span_x; ++tx, ++bit)
+        if ((accept >> bit) & 1ull) place(tx + q.min_tx, ty + q.min_ty, pair);
+  }
+  for (uint64_t todo = wide_lanes; todo != 0ull; todo &= todo - 1ull) {
+    const int gi = __shfl(i, __ffsll(static_cast<unsigned long long>(todo)) - 1);
+    const GridQuery w = grid_query(a.points + 7 * int64_t(gi), a.Wp, a.Hp, a.tile_size, a.thr);
+    const uint64_t pair = (uint64_t(depth_key(a.depth[gi], a.depth16 != 0)) << 32) | uint64_t(uint32_t(gi));
+    const int total = w.span_x * w.span_y;
+    for (int k = lane; k < total; k += 64) {
+      const int ty = k / w.span_x, tx = k - ty * w.span_x;
+      if (test_tile(w, tx, ty, a.tile_size)) place(tx + w.min_tx, ty + w.min_ty, pair);
+    }
   }
 }
 
