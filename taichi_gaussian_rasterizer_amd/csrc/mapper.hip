@@ -577,12 +577,13 @@ __device__ __forceinline__ uint64_t* lds_merge_sort(uint64_t* a, uint64_t* b, in
 }
 
 // Catch-all for buckets fuller than the wave rank sort covers (n > min_n), grid-stride over the tiles (almost
-// every tile is skipped).  n <= CAP: merge sort in LDS.  Beyond: the bitonic network in place in global memory.
+// every tile is skipped).  n <= CAP (8192): merge sort in LDS.  Beyond: the bitonic network in place in global memory.
 template <int THREADS, int CAP>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const int2* tile_ranges, uint64_t* pairs,
                                                             int* o2p, uint64_t* keys_out, int depth16, int min_n) {
-  __shared__ uint64_t s_a[CAP];
-  __shared__ uint64_t s_b[CAP];
+  extern __shared__ uint64_t s_sort[];  // 2 * CAP keys (dynamic: 128 KB of the CU's 160 KB at CAP = 8192)
+  uint64_t* s_a = s_sort;
+  uint64_t* s_b = s_sort + CAP;
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     const int2 r = tile_ranges[tile];
     const int n = r.y - r.x;
@@ -961,9 +962,14 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
     hipLaunchKernelGGL((tile_rank_sort_kernel<8>), dim3(grid), dim3(64), 0, s, num_tiles, r, pairs, overlap_to_point,
                        sorted_keys, use_depth16, skip_full);
   }
-  if (big_pass)
-    hipLaunchKernelGGL((tile_sort_kernel<1024, 4096>), dim3(min(num_tiles, 2048)), dim3(1024), 0, s, num_tiles, r,
-                       pairs, overlap_to_point, sorted_keys, use_depth16, covered);
+  if (big_pass) {
+    constexpr int CAP = 8192;
+    static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, CAP>),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CAP * 8);
+    GS_REQUIRE(lds_ok == hipSuccess, GS_ERR_LAUNCH, "gs_map_finish: cannot reserve %d bytes of LDS", 2 * CAP * 8);
+    hipLaunchKernelGGL((tile_sort_kernel<1024, CAP>), dim3(min(num_tiles, 2048)), dim3(1024), 2 * CAP * 8, s,
+                       num_tiles, r, pairs, overlap_to_point, sorted_keys, use_depth16, covered);
+  }
   GS_CHECK_LAUNCH("gs_map_finish/sort");
   return GS_OK;
 }

@@ -48,9 +48,9 @@ def test_mapper_bit_exact(seed, n, size, tile, depth16):
         assert (pu.to_np(keys).view(np.uint64) == keys_ref).all(), f"{fn.__name__}: sort keys differ"
 
 
-@pytest.mark.parametrize("n", [600, 1500, 4000, 9000])
+@pytest.mark.parametrize("n", [600, 1500, 4000, 7000, 9000])
 def test_mapper_crowded_tile(n):
-    """one tile holding more splats than the wave rank sort covers (512): workgroup merge sort in LDS up to 4096,
+    """one tile holding more splats than the wave rank sort covers (512): workgroup merge sort in LDS up to 8192,
     in-place global-memory bitonic network beyond"""
     torch.manual_seed(0)
     g2d = torch.cat([torch.rand(n, 2) * 14 + 1, torch.tensor([[1.0, 0.0]]).expand(n, 2), torch.rand(n, 2) + 0.5,
