@@ -64,9 +64,12 @@ __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, f
 #endif
 
 // LDS arena of one wave: sized by the 64-splat staging group, not by the wave's pixel region
-template <int FP, bool FULL>
+// MODE 0: lean (6 ellipse-frame moments); 1: lean + the two densification heuristics (training with statistics);
+// 2: full (7 gradients + 2 heuristics per pixel; antialiased pdf)
+template <int FP, int MODE>
 struct BwdShape {
-  static constexpr int NS = FULL ? 9 : 6;        // lean: 6 moment sums; full: 7 gradients + 2 heuristics
+  static constexpr bool FULL = MODE == 2;
+  static constexpr int NS = MODE == 2 ? 9 : MODE == 1 ? 8 : 6;
   static constexpr int NACC = NS + FP;           // values reduced per splat
   static constexpr int ROW = ((9 + FP + 15) / 16) * 16;
   static constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
@@ -75,10 +78,11 @@ struct BwdShape {
   static constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
 };
 
-template <int NB, int FP, bool FULL>
+template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, float* smem, int* s_idx) {
   const int lane = threadIdx.x;
-  constexpr int NS = FULL ? 9 : 6;        // lean: 6 moment sums; full: 7 gradients + 2 heuristics
+  constexpr bool FULL = MODE == 2, HEUR = MODE == 1;
+  constexpr int NS = MODE == 2 ? 9 : MODE == 1 ? 8 : 6;  // sums per splat besides the F feature gradients
   constexpr int NACC = NS + FP;           // values reduced per splat
   constexpr int ROW = ((9 + FP + 15) / 16) * 16;
 
@@ -256,6 +260,13 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           S[0] += G;
           S[1] += Gtx; S[2] += Gty;
           S[3] += Gtx * tx; S[4] += Gtx * ty; S[5] += Gty * ty;
+          if (HEUR) {
+            // backward.py:194-198 from the lean record: dp/dmean = p (tx A + ty B), A = axis / sx, B = perp(axis) / sy
+            const float aag = g1v.z * alpha_grad;
+            const float dmx = p * (tx * g0v.z + ty * g1v.x), dmy = p * (tx * g0v.w + ty * g1v.y);
+            S[6] += aag * aag;
+            S[7] += fabsf(aag * dmx) + fabsf(aag * dmy);
+          }
         }
       }
 
@@ -316,6 +327,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           row[4] = al * t[3] * isx;
           row[5] = al * t[5] * isy;
           row[6] = t[0];
+          if (HEUR) { row[7 + FP] = t[6]; row[8 + FP] = t[7]; }
         }
 #pragma unroll
         for (int c = 0; c < FP; ++c) row[7 + c] = t[NS + c];
@@ -340,9 +352,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 }
 
 // Block -> work: see raster_fwd_kernel (the mapper's fullest tiles get one workgroup per 8x8 quadrant).
-template <int NB, int FP, bool FULL>
+template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
-  __shared__ __attribute__((aligned(16))) float smem[BwdShape<FP, FULL>::ARENA_F];
+  __shared__ __attribute__((aligned(16))) float smem[BwdShape<FP, MODE>::ARENA_F];
   __shared__ int s_idx[64];
   const int per_tile = a.sub_x * a.sub_y;
   constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
@@ -353,7 +365,7 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
     if (NB > 1 && b < 4 * heavy) {
       tile = a.tile_order[b >> 2];
       const int x0 = (tile % a.tiles_wide) * 16 + (b & 1) * 8, y0 = (tile / a.tiles_wide) * 16 + ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, FULL>(a, tile, x0, y0, smem, s_idx);
+      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, smem, s_idx);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -369,16 +381,16 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
   const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_bwd_body<NB, FP, FULL>(a, tile, x0, y0, smem, s_idx);
+  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, smem, s_idx);
 }
 
-template <int NB, bool FULL>
+template <int NB, int MODE>
 int launch_fp(const BwdArgs& a, hipStream_t s) {
   const int grid = 8 * int(gs_div_up(a.num_items + (a.heavy ? 4 * a.heavy_cap : 0), 8));
-  if (a.F <= 3) hipLaunchKernelGGL((raster_bwd_kernel<NB, 3, FULL>), dim3(grid), dim3(64), 0, s, a);
-  else if (a.F <= 5) hipLaunchKernelGGL((raster_bwd_kernel<NB, 5, FULL>), dim3(grid), dim3(64), 0, s, a);
-  else if (a.F <= 8) hipLaunchKernelGGL((raster_bwd_kernel<NB, 8, FULL>), dim3(grid), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((raster_bwd_kernel<NB, 32, FULL>), dim3(grid), dim3(64), 0, s, a);
+  if (a.F <= 3) hipLaunchKernelGGL((raster_bwd_kernel<NB, 3, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 5) hipLaunchKernelGGL((raster_bwd_kernel<NB, 5, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 8) hipLaunchKernelGGL((raster_bwd_kernel<NB, 8, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((raster_bwd_kernel<NB, 32, MODE>), dim3(grid), dim3(64), 0, s, a);
   GS_CHECK_LAUNCH("gs_raster_bwd");
   return GS_OK;
 }
@@ -437,10 +449,10 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool full = a.aa || a.heur;
-  if (nb == 1) return full ? launch_fp<1, true>(a, s) : launch_fp<1, false>(a, s);
-  if (nb == 2) return full ? launch_fp<2, true>(a, s) : launch_fp<2, false>(a, s);
-  return full ? launch_fp<4, true>(a, s) : launch_fp<4, false>(a, s);
+  const int mode = a.aa ? 2 : a.heur ? 1 : 0;
+  if (nb == 1) return mode == 2 ? launch_fp<1, 2>(a, s) : mode == 1 ? launch_fp<1, 1>(a, s) : launch_fp<1, 0>(a, s);
+  if (nb == 2) return mode == 2 ? launch_fp<2, 2>(a, s) : mode == 1 ? launch_fp<2, 1>(a, s) : launch_fp<2, 0>(a, s);
+  return mode == 2 ? launch_fp<4, 2>(a, s) : mode == 1 ? launch_fp<4, 1>(a, s) : launch_fp<4, 0>(a, s);
 }
 
 extern "C" int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,

@@ -55,12 +55,14 @@ __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
   return gs_rcp_fast(1.0f + gs_exp2_fast(e * 1.44269504088896341f));
 }
 
-// NB: 8x8 sub-blocks per wave (1, 2 or 4; gs_raster_sub_blocks picks it from the grid size).  FP: padded feature width.  FULL: runtime switches for
-// quantile mode / visibility / antialias (the common blend-only case gets its own lean kernel).
-template <int NB, int FP, bool FULL>
+// NB: 8x8 sub-blocks per wave (1, 2 or 4; gs_raster_sub_blocks picks it from the grid size).  FP: padded feature width.
+// MODE 0: blend only (lean); 1: blend + per-splat visibility (training with pruning statistics);
+// 2: runtime switches for quantile mode / antialias (+ visibility).
+template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0,
-                                                float4 (*s_geo)[FULL ? 3 : 2], float (*s_feat)[FP], float* s_vis,
+                                                float4 (*s_geo)[MODE == 2 ? 3 : 2], float (*s_feat)[FP], float* s_vis,
                                                 int* s_idx) {
+  constexpr bool FULL = MODE == 2, VIS = MODE >= 1;
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   float Xf[NB], Yf[NB], Wt[NB], acc[NB][FP];
@@ -112,8 +114,8 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
       s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
-      if (FULL) {
-        s_geo[lane][2] = make_float4(ax, ay, isx, isy);
+      if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
+      if (VIS) {
         s_vis[lane] = 0.0f;
         s_idx[lane] = idx;
       }
@@ -177,7 +179,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         }
         vis_sum += w;
       }
-      if (FULL && a.vis) {
+      if (VIS && a.vis) {
         // forward.py:116-128: per-splat visibility = sum of blend weights over the tile's pixels
         if (__builtin_amdgcn_readfirstlane(__ballot(vis_sum != 0.0f) != 0ull)) {
           const float tot = gs_wave_sum_to_lane63(vis_sum);
@@ -185,7 +187,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         }
       }
     }
-    if (FULL && a.vis) {
+    if (VIS && a.vis) {
       __syncthreads();
       if (lane < cnt && s_vis[lane] != 0.0f) atomicAdd(a.visibility + s_idx[lane], s_vis[lane]);
     }
@@ -209,12 +211,12 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 // only) are rasterized by FOUR workgroups each, one per 8x8 quadrant, the others by workgroups of the grid's
 // own wave region -- a launch cannot end before its fullest tile has been walked by one wave, which is what
 // bounds small grids (strips of a sharded frame, training-size images).  Without an order: XCD-contiguous bands.
-template <int NB, int FP, bool FULL>
+template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
-  __shared__ float4 s_geo[64][FULL ? 3 : 2];
+  __shared__ float4 s_geo[64][MODE == 2 ? 3 : 2];
   __shared__ float s_feat[64][FP];
-  __shared__ float s_vis[FULL ? 64 : 1];
-  __shared__ int s_idx[FULL ? 64 : 1];
+  __shared__ float s_vis[MODE >= 1 ? 64 : 1];
+  __shared__ int s_idx[MODE >= 1 ? 64 : 1];
   const int per_tile = a.sub_x * a.sub_y;
   constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
   int tile, quad;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
     if (NB > 1 && b < 4 * heavy) {
       tile = a.tile_order[b >> 2];
       const int x0 = (tile % a.tiles_wide) * 16 + (b & 1) * 8, y0 = (tile / a.tiles_wide) * 16 + ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, FULL>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
+      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, MODE>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -240,16 +242,16 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
   const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
   const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_fwd_body<NB, FP, FULL>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
+  raster_fwd_body<NB, FP, MODE>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
 }
 
-template <int NB, bool FULL>
+template <int NB, int MODE>
 int launch_fp(const FwdArgs& a, hipStream_t s) {
   const int grid = 8 * int(gs_div_up(a.num_items + (a.heavy ? 4 * a.heavy_cap : 0), 8));
-  if (a.F <= 3) hipLaunchKernelGGL((raster_fwd_kernel<NB, 3, FULL>), dim3(grid), dim3(64), 0, s, a);
-  else if (a.F <= 5) hipLaunchKernelGGL((raster_fwd_kernel<NB, 5, FULL>), dim3(grid), dim3(64), 0, s, a);
-  else if (a.F <= 8) hipLaunchKernelGGL((raster_fwd_kernel<NB, 8, FULL>), dim3(grid), dim3(64), 0, s, a);
-  else hipLaunchKernelGGL((raster_fwd_kernel<NB, 32, FULL>), dim3(grid), dim3(64), 0, s, a);
+  if (a.F <= 3) hipLaunchKernelGGL((raster_fwd_kernel<NB, 3, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 5) hipLaunchKernelGGL((raster_fwd_kernel<NB, 5, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 8) hipLaunchKernelGGL((raster_fwd_kernel<NB, 8, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((raster_fwd_kernel<NB, 32, MODE>), dim3(grid), dim3(64), 0, s, a);
   GS_CHECK_LAUNCH("gs_raster_fwd");
   return GS_OK;
 }
@@ -293,8 +295,8 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   a.sat_level = 1.0f - cfg->saturate_threshold;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool full = !a.blend || a.vis || a.aa;
-  if (nb == 1) return full ? launch_fp<1, true>(a, s) : launch_fp<1, false>(a, s);
-  if (nb == 2) return full ? launch_fp<2, true>(a, s) : launch_fp<2, false>(a, s);
-  return full ? launch_fp<4, true>(a, s) : launch_fp<4, false>(a, s);
+  const int mode = (!a.blend || a.aa) ? 2 : a.vis ? 1 : 0;
+  if (nb == 1) return mode == 2 ? launch_fp<1, 2>(a, s) : mode == 1 ? launch_fp<1, 1>(a, s) : launch_fp<1, 0>(a, s);
+  if (nb == 2) return mode == 2 ? launch_fp<2, 2>(a, s) : mode == 1 ? launch_fp<2, 1>(a, s) : launch_fp<2, 0>(a, s);
+  return mode == 2 ? launch_fp<4, 2>(a, s) : mode == 1 ? launch_fp<4, 1>(a, s) : launch_fp<4, 0>(a, s);
 }
