@@ -184,6 +184,13 @@ int64_t gs_sort_scratch_bytes(int64_t k, int32_t key_bytes);
 int gs_radix_sort_pairs(int64_t k, int32_t key_bytes, const void* keys_in, const int32_t* values_in, void* keys_out,
                         int32_t* values_out, int32_t begin_bit, int32_t end_bit, void* scratch,
                         int64_t scratch_bytes, void* stream);
+/* replaces: cuda_lib.segmented_sort_pairs (cuda_lib/segmented_sort_pairs.cu:8-78; exported by the reference's
+ * native module, not called on the render path): ascending sort of the pairs inside each segment
+ * [start_offsets[s], end_offsets[s]) (int64, device); key_bytes 2 or 4 (signed keys), int32 values; stable.
+ * Positions outside every segment are not written.  scratch: 8 bytes per item. */
+int gs_segmented_sort_pairs(int64_t num_items, int32_t key_bytes, const void* keys, const int32_t* values,
+                            void* keys_out, int32_t* values_out, int64_t num_segments, const int64_t* start_offsets,
+                            const int64_t* end_offsets, void* scratch, int64_t scratch_bytes, void* stream);
 /* replaces: mapper/tile_mapper.py:91-110 find_ranges_kernel (+ zero-init :186). */
 int gs_find_ranges(int64_t k, const uint64_t* sorted_keys, int32_t use_depth16, int64_t num_tiles,
                    int32_t* tile_ranges, void* stream);

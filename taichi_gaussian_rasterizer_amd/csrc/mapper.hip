@@ -608,6 +608,46 @@ __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const
   }
 }
 
+// cuda_lib.segmented_sort_pairs (cuda_lib/segmented_sort_pairs.cu:8-78): ascending sort of (key, value) pairs inside
+// each [start, end) segment; signed 16- or 32-bit keys, int32 values.  One workgroup per segment (grid-stride) on the
+// same machinery as the crowded-tile sort: composites (biased key << 32 | position in the segment) are unique, so the
+// result is the stable order.
+template <typename K, int THREADS, int CAP>
+__global__ __launch_bounds__(THREADS) void segmented_sort_kernel(int num_segments, const int64_t* seg_start,
+                                                                 const int64_t* seg_end, const K* keys,
+                                                                 const int* values, K* keys_out, int* values_out,
+                                                                 uint64_t* scratch) {
+  extern __shared__ uint64_t s_sort[];
+  uint64_t* s_a = s_sort;
+  uint64_t* s_b = s_sort + CAP;
+  const int t = threadIdx.x;
+  const uint32_t bias = sizeof(K) == 2 ? 0x8000u : 0x80000000u;  // signed -> unsigned order
+  for (int seg = blockIdx.x; seg < num_segments; seg += gridDim.x) {
+    const int64_t lo = seg_start[seg];
+    const int n = int(seg_end[seg] - lo);
+    if (n <= 0) continue;
+    uint64_t* stage = n <= CAP ? s_a : scratch + lo;
+    for (int i = t; i < n; i += THREADS) {
+      const uint32_t k = (sizeof(K) == 2 ? uint32_t(uint16_t(keys[lo + i])) : uint32_t(keys[lo + i])) ^ bias;
+      stage[i] = (uint64_t(k) << 32) | uint64_t(uint32_t(i));
+    }
+    const uint64_t* data;
+    if (n <= CAP) {
+      data = lds_merge_sort<THREADS, CAP>(s_a, s_b, n, t);
+    } else {
+      __syncthreads();
+      bitonic_sort<THREADS>(stage, n, t);
+      data = stage;
+    }
+    for (int i = t; i < n; i += THREADS) {
+      const uint64_t kv = data[i];
+      keys_out[lo + i] = K(uint32_t(kv >> 32) ^ bias);
+      values_out[lo + i] = values[lo + int(uint32_t(kv))];
+    }
+    __syncthreads();
+  }
+}
+
 // Rank sort, one WAVE per tile, for buckets of up to 64*R pairs (the common case: a few hundred
 // splats per tile).  Keys are unique (the Gaussian index is the low word), so the rank of a key
 // -- the number of keys below it -- is its final position.  Each lane keeps R keys in registers
@@ -971,6 +1011,41 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
                        num_tiles, r, pairs, overlap_to_point, sorted_keys, use_depth16, covered);
   }
   GS_CHECK_LAUNCH("gs_map_finish/sort");
+  return GS_OK;
+}
+
+extern "C" int gs_segmented_sort_pairs(int64_t num_items, int32_t key_bytes, const void* keys, const int32_t* values,
+                                       void* keys_out, int32_t* values_out, int64_t num_segments,
+                                       const int64_t* start_offsets, const int64_t* end_offsets, void* scratch,
+                                       int64_t scratch_bytes, void* stream) {
+  GS_REQUIRE(key_bytes == 2 || key_bytes == 4, GS_ERR_UNSUPPORTED,
+             "gs_segmented_sort_pairs: %d-byte keys (int16 and int32 are implemented, as in the reference)", key_bytes);
+  GS_REQUIRE(num_items >= 0 && num_items < (int64_t(1) << 31) && num_segments >= 0, GS_ERR_INVALID_ARGUMENT,
+             "gs_segmented_sort_pairs: %lld items, %lld segments", (long long)num_items, (long long)num_segments);
+  if (num_items == 0 || num_segments == 0) return GS_OK;
+  GS_REQUIRE(keys && values && keys_out && values_out && start_offsets && end_offsets, GS_ERR_INVALID_ARGUMENT,
+             "gs_segmented_sort_pairs: NULL buffer");
+  GS_REQUIRE(scratch && scratch_bytes >= num_items * 8, GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_segmented_sort_pairs: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)num_items * 8);
+  constexpr int CAP = 8192;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const dim3 grid(unsigned(num_segments < 4096 ? num_segments : 4096));
+  if (key_bytes == 4) {
+    static const hipError_t ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&segmented_sort_kernel<int32_t, 1024, CAP>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CAP * 8);
+    GS_REQUIRE(ok == hipSuccess, GS_ERR_LAUNCH, "gs_segmented_sort_pairs: cannot reserve LDS");
+    hipLaunchKernelGGL((segmented_sort_kernel<int32_t, 1024, CAP>), grid, dim3(1024), 2 * CAP * 8, s, int(num_segments),
+                       start_offsets, end_offsets, static_cast<const int32_t*>(keys), values,
+                       static_cast<int32_t*>(keys_out), values_out, static_cast<uint64_t*>(scratch));
+  } else {
+    static const hipError_t ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&segmented_sort_kernel<int16_t, 1024, CAP>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CAP * 8);
+    GS_REQUIRE(ok == hipSuccess, GS_ERR_LAUNCH, "gs_segmented_sort_pairs: cannot reserve LDS");
+    hipLaunchKernelGGL((segmented_sort_kernel<int16_t, 1024, CAP>), grid, dim3(1024), 2 * CAP * 8, s, int(num_segments),
+                       start_offsets, end_offsets, static_cast<const int16_t*>(keys), values,
+                       static_cast<int16_t*>(keys_out), values_out, static_cast<uint64_t*>(scratch));
+  }
+  GS_CHECK_LAUNCH("gs_segmented_sort_pairs");
   return GS_OK;
 }
 

@@ -91,8 +91,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   // instead of ~11.5 KB, i.e. 21 instead of 13 resident waves per CU.
   constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
   constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
-  constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
-  constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
+  constexpr int OUT_STRIDE = ROW + 1;  // the arena itself is sized by BwdShape (same formulas)
   float4(*s_geo)[GEO_V4] = reinterpret_cast<float4(*)[GEO_V4]>(smem);
   float(*s_feat)[FP] = reinterpret_cast<float(*)[FP]>(smem + GEO_F);
   float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + GEO_F + FEAT_F);

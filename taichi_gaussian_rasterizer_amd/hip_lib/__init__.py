@@ -58,10 +58,39 @@ def radix_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_bit=0, end_
     return keys_out, values_out
 
 
+def segmented_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_offset: torch.Tensor,
+                         end_offset: torch.Tensor):
+    """Ascending sort of (key, value) pairs inside each segment [start_offset[s], end_offset[s]); returns new
+    tensors (reference cuda_lib/segmented_sort_pairs.cu:36-78: int32 or int16 keys, int32 values, int64 offsets).
+    Stable; positions outside every segment keep the input pair."""
+    for name, t in (("keys", keys), ("values", values), ("start_offset", start_offset), ("end_offset", end_offset)):
+        assert t.is_cuda, f"{name}: device must be a cuda device, got {t.device}"
+    assert keys.dim() == 1 and values.dim() == 1 and keys.shape[0] == values.shape[0], \
+        "keys and values must be 1D and have the same size"
+    assert start_offset.dim() == 1 and end_offset.dim() == 1 and start_offset.shape[0] == end_offset.shape[0], \
+        "start_offset and end_offset must be 1D and have the same size"
+    assert start_offset.dtype == torch.int64 and end_offset.dtype == torch.int64, \
+        "start_offset/end_offset must be int64"
+    if keys.dtype not in (torch.int32, torch.int16) or values.dtype != torch.int32:
+        raise RuntimeError("Not yet implemented for data type.")  # reference segmented_sort_pairs.cu:76
+    lib = nv.lib()
+    keys, values = keys.contiguous(), values.contiguous()
+    keys_out, values_out = keys.clone(), values.clone()
+    n, segs = keys.shape[0], start_offset.shape[0]
+    if n == 0 or segs == 0:
+        return keys_out, values_out
+    scratch = torch.empty((n * 8,), dtype=torch.uint8, device=keys.device)
+    nv.check(lib.gs_segmented_sort_pairs(n, keys.element_size(), nv.ptr(keys), nv.ptr(values), nv.ptr(keys_out),
+                                         nv.ptr(values_out), segs, nv.ptr(start_offset.contiguous()),
+                                         nv.ptr(end_offset.contiguous()), nv.ptr(scratch), n * 8, nv.stream()),
+             "gs_segmented_sort_pairs")
+    return keys_out, values_out
+
+
 def radix_argsort(keys: torch.Tensor):
     idx = torch.arange(keys.shape[0], dtype=torch.int32, device=keys.device)
     _, idx = radix_sort_pairs(keys, idx)
     return idx
 
 
-__all__ = ["full_cumsum", "radix_sort_pairs", "radix_argsort"]
+__all__ = ["full_cumsum", "radix_sort_pairs", "segmented_sort_pairs", "radix_argsort"]

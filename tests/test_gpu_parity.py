@@ -97,6 +97,29 @@ def test_hip_lib_cumsum_and_sort():
         gs.hip_lib.full_cumsum(torch.zeros(4, device=DEV))
 
 
+@pytest.mark.parametrize("dtype", [torch.int32, torch.int16])
+def test_hip_lib_segmented_sort_pairs(dtype):
+    """cuda_lib.segmented_sort_pairs (reference cuda_lib/__init__.py:27,47-56): per-segment ascending sort of signed
+    keys, against torch.sort; a gap between segments, an empty segment, one beyond the LDS capacity"""
+    gen = torch.Generator().manual_seed(0)
+    bounds = [0, 8, 16, 16, 700, 9800, 30000]          # segment s = [bounds[s], bounds[s+1]) except the gap below
+    starts = torch.tensor(bounds[:-1], dtype=torch.int64)
+    ends = torch.tensor(bounds[1:], dtype=torch.int64)
+    ends[0] = 6                                         # items 6, 7 belong to no segment
+    n = bounds[-1]
+    lim = 30000 if dtype == torch.int16 else 2 ** 31 - 1
+    k = torch.randint(-lim, lim, (n,), generator=gen).to(dtype)
+    v = torch.arange(n, dtype=torch.int32)
+    ko, vo = gs.hip_lib.segmented_sort_pairs(dev(k), dev(v), dev(starts), dev(ends))
+    ko, vo = ko.cpu(), vo.cpu()
+    for a, b in zip(starts.tolist(), ends.tolist()):
+        ref, order = torch.sort(k[a:b].long(), stable=True)
+        assert torch.equal(ko[a:b].long(), ref) and torch.equal(vo[a:b].long(), order + a)
+    assert torch.equal(ko[6:8], k[6:8]) and torch.equal(vo[6:8], v[6:8])
+    with pytest.raises(RuntimeError):
+        gs.hip_lib.segmented_sort_pairs(dev(k.long()), dev(v), dev(starts), dev(ends))
+
+
 # -------------------------------------------------------------------------------- rasterizer
 RASTER_CASES = [(0, 40, (8, 8), 8, 3), (1, 300, (64, 48), 16, 3), (2, 500, (50, 37), 16, 1), (3, 64, (33, 17), 8, 2),
                 (4, 1000, (96, 64), 32, 3), (5, 4000, (320, 200), 16, 5), (6, 800, (128, 72), 16, 8),
