@@ -90,7 +90,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   // by the time the gradient rows (out) are written, so `out` aliases them: ~7.4 KB per wave
   // instead of ~11.5 KB, i.e. 21 instead of 13 resident waves per CU.
   constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
-  constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
+  constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1;
   constexpr int OUT_STRIDE = ROW + 1;  // the arena itself is sized by BwdShape (same formulas)
   float4(*s_geo)[GEO_V4] = reinterpret_cast<float4(*)[GEO_V4]>(smem);
   float(*s_feat)[FP] = reinterpret_cast<float(*)[FP]>(smem + GEO_F);
