@@ -83,6 +83,15 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
   const float k_exp = 0.84932180028801904f;  // sqrt(0.5 * log2(e)): exp(-0.5 t^2) = exp2(-(k t)^2)
 
   for (int g0 = range.x; g0 < range.y; g0 += 64) {
+    // The reference's forward never stops (forward.py:84-128).  Once every pixel of the region has less than
+    // 2^-20 of its transmittance left, everything still to come changes a pixel by < 1e-6 in total (features are
+    // clamped colours; 20x below the parity tolerance), so the rest of a crowded tile's list is skipped.
+    if (!FULL || a.blend) {
+      bool open = false;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) open |= Wt[b] < 1.0f - 9.5367431640625e-07f;
+      if (__ballot(open) == 0ull) break;
+    }
     const int cnt = min(64, range.y - g0);
     // ---- stage up to 64 splats: lane j <- splat g0 + j
     if (lane < cnt) {

@@ -643,7 +643,10 @@ def test_fused_frame_splits_heavy_tiles(nb, monkeypatch):
     a = g.to(DEV).requires_grad_(True)
     r = gs.render_gaussians(a, cam, cfg, use_sh=True)
     (r.image * gi).sum().backward()
-    assert torch.equal(r.image, r2.image) and torch.equal(r.image_weight, r2.image_weight)
+    # same per-pixel arithmetic; only the saturation cut (all pixels of a wave's region below 2^-20 transmittance)
+    # can fall at a different splat for an 8x8 quadrant than for the whole region: < 1e-6 per pixel
+    assert torch.allclose(r.image, r2.image, rtol=0, atol=2e-6)
+    assert torch.allclose(r.image_weight, r2.image_weight, rtol=0, atol=2e-6)
     for k, t in a.items():
         pu.assert_grad_close(t.grad, getattr(b, k).grad, f"grad {k} with split tiles", tol=1e-3)
 
