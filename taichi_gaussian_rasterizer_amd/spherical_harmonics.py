@@ -65,7 +65,17 @@ def evaluate_sh_at(sh_params: torch.Tensor,   # M, K, (degree + 1)^2  (usually K
             raise TypeError(f"{name} must be a torch.Tensor, got {type(t).__name__}")
     degree = check_sh_degree(sh_params)
     assert 0 <= degree <= 3, f"SH degree must be between 0 and 3, got {degree}"
-    unique = bool(getattr(indexes, "_gs_unique", False))
+    unique = getattr(indexes, "_gs_unique", None)
+    if unique is None and sh_params.requires_grad and indexes.is_cuda and indexes.shape[0] > 1:
+        # strictly ascending indexes (an arange, any sorted visible list) hit every row at most once: the backward
+        # can then store gradient rows instead of adding 48 floats per Gaussian atomically (10x faster).  One
+        # device read per index tensor; the verdict is cached on the tensor.
+        unique = bool((indexes[1:] > indexes[:-1]).all().item())
+        try:
+            indexes._gs_unique = unique
+        except AttributeError:
+            pass
+    unique = bool(unique)
     slot_of = getattr(indexes, "_gs_slot_of", None)  # inverse of the projection's visible list
     if slot_of is not None and slot_of.shape[0] != sh_params.shape[0]:
         slot_of = None
