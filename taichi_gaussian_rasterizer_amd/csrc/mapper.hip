@@ -536,27 +536,51 @@ __device__ __forceinline__ void bitonic_sort(uint64_t* data, int n, int t) {
   }
 }
 
-// Merge sort of one crowded bucket (n <= CAP keys) in LDS by a whole workgroup.  Runs of 64 are ranked the way
-// the wave rank sort does it (every key of the run broadcast once); then runs are merged pairwise, each key
-// finding its place by a lower bound in the partner run (keys are unique), ping-pong between two LDS buffers:
-// n (6 + log2(n/64) (log2(n/64) + 13) / 2) probes in all -- 0.27 M for 4096 keys, against 2.4 M compare-exchanges
-// and 78 barriers for the bitonic network.
+// Merge sort of one crowded bucket (n <= CAP keys) in LDS by a whole workgroup.  Chunks of 256 are sorted by one
+// wave each the way the wave rank sort does it; then runs are merged pairwise, each key finding its place by a
+// lower bound in the partner run (keys are unique), ping-pong between two LDS buffers: log2(n / 256) barriers,
+// against 78 for the bitonic network at 4096 keys.
 template <int THREADS, int CAP>
 __device__ __forceinline__ uint64_t* lds_merge_sort(uint64_t* a, uint64_t* b, int n, int t) {
-  const int np = (n + 63) & ~63;  // pad to whole runs with unique keys above every real one
+  const int np = (n + 255) & ~255;  // pad to whole chunks with unique keys above every real one
   for (int i = n + t; i < np; i += THREADS) a[i] = 0xFFFFFFFF00000000ull | uint64_t(i);
   __syncthreads();
-  for (int i = t; i < np; i += THREADS) {
-    const uint64_t mine = a[i];
-    const uint64_t* run = a + (i & ~63);
-    int rank = 0;
-    for (int j = 0; j < 64; ++j) rank += run[j] < mine ? 1 : 0;  // wave-uniform address: an LDS broadcast
-    b[(i & ~63) + rank] = mine;
+  // chunks of 256: one wave each, the two-level rank sort of rank_sort_rows<4> (rows of 64 against themselves,
+  // lower bounds across the four rows), a -> b.  Only the wave's own chunk is touched, so no workgroup barrier.
+  const int lane = t & 63;
+  for (int base = (t >> 6) * 256; base < np; base += (THREADS >> 6) * 256) {
+    uint64_t* chunk = a + base;
+    uint64_t mine[4];
+    int rank[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { mine[q] = chunk[q * 64 + lane]; rank[q] = 0; }
+    for (int j = 0; j < 64; ++j) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) rank[q] += chunk[q * 64 + j] < mine[q] ? 1 : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) chunk[q * 64 + rank[q]] = mine[q];
+    __asm__ volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes, before its lanes read them
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        if (p == q) continue;
+        const uint64_t* row = chunk + p * 64;
+        int pos = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) pos += row[pos + step - 1] < mine[q] ? step : 0;
+        pos += row[pos] < mine[q] ? 1 : 0;
+        rank[q] += pos;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) b[base + rank[q]] = mine[q];
   }
   __syncthreads();
   uint64_t* src = b;
   uint64_t* dst = a;
-  for (int width = 64; width < np; width <<= 1) {
+  for (int width = 256; width < np; width <<= 1) {
     for (int i = t; i < np; i += THREADS) {
       const uint64_t mine = src[i];
       const int run = i / width, pos = i - run * width;
@@ -577,17 +601,18 @@ __device__ __forceinline__ uint64_t* lds_merge_sort(uint64_t* a, uint64_t* b, in
 }
 
 // Catch-all for buckets fuller than the wave rank sort covers (n > min_n), grid-stride over the tiles (almost
-// every tile is skipped).  n <= CAP (8192): merge sort in LDS.  Beyond: the bitonic network in place in global memory.
+// every tile is skipped).  n <= CAP: merge sort in LDS.  Beyond: the bitonic network in place in global memory.
 template <int THREADS, int CAP>
 __global__ __launch_bounds__(THREADS) void tile_sort_kernel(int num_tiles, const int2* tile_ranges, uint64_t* pairs,
-                                                            int* o2p, uint64_t* keys_out, int depth16, int min_n) {
+                                                            int* o2p, uint64_t* keys_out, int depth16, int min_n,
+                                                            int max_n) {
   extern __shared__ uint64_t s_sort[];  // 2 * CAP keys (dynamic: 128 KB of the CU's 160 KB at CAP = 8192)
   uint64_t* s_a = s_sort;
   uint64_t* s_b = s_sort + CAP;
   for (int tile = blockIdx.x; tile < num_tiles; tile += gridDim.x) {
     const int2 r = tile_ranges[tile];
     const int n = r.y - r.x;
-    if (n <= min_n) continue;  // uniform over the workgroup
+    if (n <= min_n || n > max_n) continue;  // uniform over the workgroup; another launch covers the rest
     uint64_t* seg = pairs + r.x;
     const int t = threadIdx.x;
     const uint64_t* data = seg;
@@ -1003,12 +1028,25 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
                        sorted_keys, use_depth16, skip_full);
   }
   if (big_pass) {
-    constexpr int CAP = 8192;
+    // 513 .. 1024 and 1025 .. 2048 pairs: 256-thread workgroups with 16 / 32 KB of LDS (ten / five per CU -- in dense
+    // scenes most tiles are here); above that: 1024 threads and 128 KB (one per CU).  A size class is launched only
+    // when such tiles are expected.
+    constexpr int SMALL = 1024, MID = 2048, CAP = 8192;
+    const bool mid_pass = guess > SMALL, huge_pass = guess > MID;
     static const hipError_t lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_sort_kernel<1024, CAP>),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * CAP * 8);
     GS_REQUIRE(lds_ok == hipSuccess, GS_ERR_LAUNCH, "gs_map_finish: cannot reserve %d bytes of LDS", 2 * CAP * 8);
-    hipLaunchKernelGGL((tile_sort_kernel<1024, CAP>), dim3(min(num_tiles, 2048)), dim3(1024), 2 * CAP * 8, s,
-                       num_tiles, r, pairs, overlap_to_point, sorted_keys, use_depth16, covered);
+    // each launch takes the sizes the later ones do not cover (the last one launched takes everything above)
+    hipLaunchKernelGGL((tile_sort_kernel<256, SMALL>), dim3(min(num_tiles, 8192)), dim3(256), 2 * SMALL * 8, s,
+                       num_tiles, r, pairs, overlap_to_point, sorted_keys, use_depth16, covered,
+                       mid_pass ? SMALL : 0x7fffffff);
+    if (mid_pass)
+      hipLaunchKernelGGL((tile_sort_kernel<256, MID>), dim3(min(num_tiles, 8192)), dim3(256), 2 * MID * 8, s,
+                         num_tiles, r, pairs, overlap_to_point, sorted_keys, use_depth16, SMALL,
+                         huge_pass ? MID : 0x7fffffff);
+    if (huge_pass)
+      hipLaunchKernelGGL((tile_sort_kernel<1024, CAP>), dim3(min(num_tiles, 2048)), dim3(1024), 2 * CAP * 8, s,
+                         num_tiles, r, pairs, overlap_to_point, sorted_keys, use_depth16, MID, 0x7fffffff);
   }
   GS_CHECK_LAUNCH("gs_map_finish/sort");
   return GS_OK;

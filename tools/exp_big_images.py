@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, '.')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, taichi_gaussian_rasterizer_amd as gs
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes
 for size, n in (((8192, 4096), 2_000_000), ((16000, 300), 300_000), ((300, 9000), 300_000)):

@@ -1,6 +1,6 @@
 """C3 frame under other RasterConfig settings (tile size, antialias, visibility + heuristics, depth16)"""
 import sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import taichi_gaussian_rasterizer_amd as gs
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, _native as nv

@@ -1,6 +1,6 @@
 """rasterizer wave-region variants (GS_RASTER_NB = 1 | 2 | 4 sub-blocks per wave) across image sizes"""
 import os, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import taichi_gaussian_rasterizer_amd as gs
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, _native as nv

@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
 import torch, torch.distributed as dist
 torch.cuda.set_device(0)

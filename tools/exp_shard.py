@@ -1,6 +1,6 @@
 """per-rank stage times of a sharded frame, emulated on one GPU (no process group: the all-reduce is a no-op)"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import taichi_gaussian_rasterizer_amd as gs
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, parallel, _native as nv

@@ -1,6 +1,6 @@
 """raster stage times of one rank's strip of the C3 frame (emulated, no collective) for each wave-region variant"""
 import os, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, parallel, _native as nv
 n, size = 1_000_000, (2048, 2048)

@@ -1,6 +1,6 @@
 """a frame with a dense cluster (20 % of the Gaussians inside 3 % of the screen): heavy-tile split on / off"""
 import os, sys
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import taichi_gaussian_rasterizer_amd as gs
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, _native as nv
