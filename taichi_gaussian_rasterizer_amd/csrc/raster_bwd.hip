@@ -126,10 +126,13 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 
   for (int g0 = range.x; g0 < range.y; g0 += 64) {
     // all pixels of the region saturated -> nothing further contributes (backward.py:116-118)
-    bool any_alive = false;
+    // ... and a saturated 8x8 sub-block takes no gradient from here on (:160,166): masked out before its alphas
+    // are even computed
+    int live = 0;
 #pragma unroll
-    for (int b = 0; b < NB; ++b) any_alive |= Wt[b] < a.sat;
-    if (__ballot(any_alive) == 0ull) break;
+    for (int b = 0; b < NB; ++b)
+      if (__ballot(Wt[b] < a.sat) != 0ull) live |= 1 << b;
+    if (live == 0) break;
 
     const int cnt = min(64, range.y - g0);
     float ax = 0, ay = 0, isx = 0, isy = 0, al = 0;
@@ -174,7 +177,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 
     for (int j = 0; j < cnt; ++j) {
       const float4 g0v = s_geo[j][0], g1v = s_geo[j][1];
-      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
+      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
       float4 g2v = make_float4(0, 0, 0, 0);
       if (FULL) g2v = s_geo[j][2];
       float feat[FP];

@@ -86,11 +86,14 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
     // The reference's forward never stops (forward.py:84-128).  Once every pixel of the region has less than
     // 2^-20 of its transmittance left, everything still to come changes a pixel by < 1e-6 in total (features are
     // clamped colours; 20x below the parity tolerance), so the rest of a crowded tile's list is skipped.
+    // The same holds per 8x8 sub-block: a saturated one is masked out for the rest of the list.
+    int live = (1 << NB) - 1;
     if (!FULL || a.blend) {
-      bool open = false;
+      live = 0;
 #pragma unroll
-      for (int b = 0; b < NB; ++b) open |= Wt[b] < 1.0f - 9.5367431640625e-07f;
-      if (__ballot(open) == 0ull) break;
+      for (int b = 0; b < NB; ++b)
+        if (__ballot(Wt[b] < 1.0f - 9.5367431640625e-07f) != 0ull) live |= 1 << b;
+      if (live == 0) break;
     }
     const int cnt = min(64, range.y - g0);
     // ---- stage up to 64 splats: lane j <- splat g0 + j
@@ -154,7 +157,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 #pragma unroll
         for (int c = 0; c < FP; ++c) nfeat[c] = s_feat[jn][c];
       }
-      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w));
+      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
       float vis_sum = 0.0f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
