@@ -137,3 +137,30 @@ def test_install_as_taichi_splatting():
     assert taichi_splatting is gs and C2 is CameraParams
     for k in [k for k in sys.modules if k == "taichi_splatting" or k.startswith("taichi_splatting.")]:
         del sys.modules[k]
+
+
+def test_renderer2d_split_helpers_cpu():
+    """the 2D example's densification helpers (reference misc/renderer2d.py:60-132): shapes, shrink factors, offsets
+    inside the parent's frame"""
+    import math
+    from taichi_gaussian_rasterizer_amd import scenes
+    from taichi_gaussian_rasterizer_amd.misc import renderer2d as r2d
+    torch.manual_seed(0)
+    g = scenes.random_2d_gaussians(50, (64, 48))
+    s = r2d.split_gaussians2d(g, n=3)
+    assert s.batch_size[0] == 150 and s.position.shape == (150, 2)
+    assert torch.allclose(s.log_scaling, g.log_scaling.repeat_interleave(3, 0) + math.log(1 / math.sqrt(3)))
+    assert (s.z_depth > 0).all() and torch.equal(s.feature, g.feature.repeat_interleave(3, 0))
+    u = r2d.uniform_split_gaussians2d(g, n=2, sep=0.7)
+    assert u.batch_size[0] == 100
+    long_axis = torch.argmax(g.log_scaling, dim=1)
+    ratio = (u.scaling / g.scaling.repeat_interleave(2, 0))
+    picked = ratio.gather(1, long_axis.repeat_interleave(2).unsqueeze(1)).squeeze(1)
+    assert torch.allclose(picked, torch.full_like(picked, math.sqrt(2) / 2), atol=1e-5)
+    # the two copies sit at -sep and +sep sigma along the parent's long axis: their midpoint is the parent
+    mid = u.position.view(50, 2, 2).mean(1)
+    assert torch.allclose(mid, g.position, atol=1e-4)
+    off = r2d.sample_gaussians(g)
+    assert off.shape == (50, 2) and torch.isfinite(off).all()
+    cov = r2d.point_covariance(g)
+    assert torch.allclose(cov, cov.transpose(1, 2), atol=1e-5) and (torch.linalg.eigvalsh(cov) > 0).all()
