@@ -1,62 +1,45 @@
-"""project_to_image forward and backward (reference benchmarks/bench_projection.py: same flags, same phases)."""
+"""Projection operator: forward, and backward with respect to the Gaussians / the extrinsics / the intrinsics / all
+(the phases of the reference's benchmarks/bench_projection.py)."""
 from __future__ import annotations
-
-import argparse
 
 import torch
 
 from ..data_types import RasterConfig
 from ..perspective import projection
 from ..scenes import random_3d_gaussians, random_camera
-from .util import benchmarked, image_size_arg
+from .util import Phases, clear_grads, make_parser
 
-
-def parse_args(args=None):
-    p = argparse.ArgumentParser()
-    p.add_argument("--profile", action="store_true")
-    p.add_argument("--image_size", type=str, default="1024,768")
-    p.add_argument("--device", type=str, default="cuda:0")
-    p.add_argument("--n", type=int, default=2000000)
-    p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--iters", type=int, default=1000)
-    p.add_argument("--margin", type=float, default=0.5, help="controls random points (non visible) margin")
-    p.add_argument("--debug", action="store_true")
-    ns = p.parse_args(args)
-    ns.image_size = image_size_arg(ns.image_size)
-    return ns
+parse_args = make_parser(("profile", "image_size", "device", "n", "seed", "iters", "margin", "debug"), n=2000000)
 
 
 def bench_projection(args):
     torch.manual_seed(args.seed)
-    results = {}
     camera = random_camera(image_size=args.image_size)
-    gaussians = random_3d_gaussians(args.n, camera, margin=args.margin).to(args.device)
+    scene = random_3d_gaussians(args.n, camera, margin=args.margin).to(args.device)
     camera = camera.to(device=args.device)
-    config = RasterConfig()
-    with torch.no_grad():
-        _, _, visible = projection.project_to_image(gaussians, camera, config)
-        print(args)
-        print(f"benchmarking {args.n} points ({visible.shape[0]} visible) points")
-        results["forward"] = benchmarked("forward", lambda: projection.project_to_image(gaussians, camera, config),
-                                         profile=args.profile, iters=args.iters)
+    config, phases = RasterConfig(), Phases(args)
+    leaves = (*scene.shape_tensors(), camera.T_camera_world, camera.projection)
 
-    def backward():
-        for t in (*gaussians.shape_tensors(), camera.T_camera_world, camera.projection):
-            t.grad = None
-        points, depth, _ = projection.project_to_image(gaussians, camera, config)
+    def project():
+        return projection.project_to_image(scene, camera, config)
+
+    def project_and_differentiate():
+        clear_grads(*leaves)
+        points, depth, _ = project()
         (points.sum() + depth.sum()).backward()
 
-    gaussians.requires_grad_(True)
-    results["backward (gaussians)"] = benchmarked("backward (gaussians)", backward, profile=args.profile,
-                                                  iters=args.iters)
-    for name, extrinsics, intrinsics, splats in (("backward (extrinsics)", True, False, False),
-                                                 ("backward (intrinsics)", False, True, False),
-                                                 ("backward (everything)", True, True, True)):
-        gaussians.requires_grad_(splats)
-        camera.T_camera_world.requires_grad_(extrinsics)
-        camera.projection.requires_grad_(intrinsics)
-        results[name] = benchmarked(name, backward, profile=args.profile, iters=args.iters)
-    return results
+    with torch.no_grad():
+        print(args)
+        print(f"benchmarking {args.n} points ({project()[2].shape[0]} visible) points")
+        phases.run("forward", project)
+    #             phase                     gaussians  extrinsics  intrinsics
+    for name, wrt in (("backward (gaussians)", (True, False, False)), ("backward (extrinsics)", (False, True, False)),
+                      ("backward (intrinsics)", (False, False, True)), ("backward (everything)", (True, True, True))):
+        scene.requires_grad_(wrt[0])
+        camera.T_camera_world.requires_grad_(wrt[1])
+        camera.projection.requires_grad_(wrt[2])
+        phases.run(name, project_and_differentiate)
+    return phases.results
 
 
 def main():

@@ -1,53 +1,39 @@
-"""evaluate_sh_at forward and backward (reference benchmarks/bench_sh.py: same flags, same phases)."""
+"""Spherical-harmonics colour operator: forward, backward to the coefficients, backward to everything
+(the phases of the reference's benchmarks/bench_sh.py)."""
 from __future__ import annotations
-
-import argparse
 
 import torch
 
-from .. import spherical_harmonics
-from .util import benchmarked, image_size_arg
+from ..spherical_harmonics import evaluate_sh_at
+from .util import Phases, clear_grads, make_parser
 
-
-def parse_args(args=None):
-    p = argparse.ArgumentParser()
-    p.add_argument("--profile", action="store_true")
-    p.add_argument("--image_size", type=str, default="1024,768")
-    p.add_argument("--device", type=str, default="cuda:0")
-    p.add_argument("--n", type=int, default=1000000)
-    p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--iters", type=int, default=200)
-    p.add_argument("--degree", type=int, default=3)
-    p.add_argument("--debug", action="store_true")
-    ns = p.parse_args(args)
-    ns.image_size = image_size_arg(ns.image_size)
-    return ns
+parse_args = make_parser(("profile", "image_size", "device", "n", "seed", "iters", "degree", "debug"), iters=200)
 
 
 def bench_sh(args):
     torch.manual_seed(args.seed)
-    results = {}
-    sh_features = torch.randn(args.n, 3, (args.degree + 1) ** 2, device=args.device)
-    points = torch.randn(args.n, 3, device=args.device)
-    indexes = torch.arange(args.n, device=args.device)
-    camera_pos = torch.zeros(3, device=args.device)
+    on = dict(device=args.device)
+    coefficients = torch.randn(args.n, 3, (args.degree + 1) ** 2, **on)
+    centres = torch.randn(args.n, 3, **on)
+    everyone = torch.arange(args.n, **on)
+    eye = torch.zeros(3, **on)
+    phases = Phases(args)
+
+    def colours():
+        return evaluate_sh_at(coefficients, centres, everyone, eye)
+
+    def colours_and_gradients():
+        clear_grads(coefficients, centres, eye)
+        colours().sum().backward()
+
     with torch.no_grad():
-        results["forward"] = benchmarked(
-            "forward", lambda: spherical_harmonics.evaluate_sh_at(sh_features, points, indexes, camera_pos),
-            profile=args.profile, iters=args.iters)
-
-    def backward():
-        for t in (sh_features, points, camera_pos):
-            t.grad = None
-        spherical_harmonics.evaluate_sh_at(sh_features, points, indexes, camera_pos).sum().backward()
-
-    sh_features.requires_grad_(True)
-    results["backward (sh_features)"] = benchmarked("backward (sh_features)", backward, profile=args.profile,
-                                                    iters=args.iters)
-    points.requires_grad_(True)
-    camera_pos.requires_grad_(True)
-    results["backward (all)"] = benchmarked("backward (all)", backward, profile=args.profile, iters=args.iters)
-    return results
+        phases.run("forward", colours)
+    coefficients.requires_grad_(True)
+    phases.run("backward (sh_features)", colours_and_gradients)
+    centres.requires_grad_(True)
+    eye.requires_grad_(True)
+    phases.run("backward (all)", colours_and_gradients)
+    return phases.results
 
 
 def main():
