@@ -258,6 +258,12 @@ int gs_morton_codes64(int64_t n, const float* points, const float* lower_host, f
  * param[idx] -= lr_step * (1 - exp(-2 weight)) * mask_lr[j] * point_lr[idx] (optim/fractional.py:31-32, :57-63,
  * :139-146; mask_lr (dims), point_lr (N) optional), in which case lr_step itself may be NULL.
  */
+/* replaces: optim/visibility_aware.py:24-31 (update_visibility) + :93-103 of VisibilityOptimizer.step for the visible
+ * rows (indexes unique): running_vis[idx] <- (v^4 + (running^4 - v^4) vis_beta)^(1/4); weight[i] = v / max(running, 1e-12);
+ * total_weight[idx] += weight[i]; row_scale[i] = grad_scale / (v + vis_smooth)  (the latter two feed gs_optim_step). */
+int gs_optim_visibility_weights(int64_t rows, const int64_t* indexes, const float* visibility, float* running_vis,
+                                float* total_weight, float vis_beta, float grad_scale, float vis_smooth, float* weight,
+                                float* row_scale, void* stream);
 int gs_optim_step(int32_t laprop, int32_t vector_group, int64_t rows, int32_t dims, const int64_t* indexes,
                   const float* weight, float* m, float* v, const float* total_weight, const float* grad, float lr,
                   float beta1, float beta2, float eps, int32_t bias_correction, float* lr_step,

@@ -61,6 +61,7 @@ SIGNATURES = {
     "gs_raster_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _P]),
     "gs_raster_bwd_unpack": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _P]),
     "gs_segmented_sort_pairs": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _P]),
+    "gs_optim_visibility_weights": (ctypes.c_int, [_I64, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]),
     "gs_optim_step": (ctypes.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float,
                                       _I32, _P, _P, _P, _P, _P, _P]),
     "gs_morton_codes64": (ctypes.c_int, [_I64, _P, _P, c_float, _I32, _P, _P]),

@@ -119,7 +119,41 @@ __global__ __launch_bounds__(256) void optim_vector_kernel(OptArgs a) {
   a.v[idx] = v;
 }
 
+// Per-view pacing of the visibility-aware optimizers (optim/visibility_aware.py:24-31, :93-103) for the visible rows:
+// running visibility <- power mean (p = 4) of the view's visibility and the history; step weight = visibility /
+// running; total_weight += weight; gradient scale = grad_scale / (visibility + vis_smooth).
+__global__ __launch_bounds__(256) void visibility_weights_kernel(int64_t rows, const int64_t* indexes,
+                                                                 const float* visibility, float* running_vis,
+                                                                 float* total_weight, float vis_beta, float grad_scale,
+                                                                 float vis_smooth, float* weight, float* row_scale) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= rows) return;
+  const int64_t idx = indexes[i];
+  const float vis = visibility[i], old = running_vis[idx];
+  const float v2 = vis * vis, o2 = old * old;
+  const float v4 = v2 * v2, o4 = o2 * o2;
+  const float now = sqrtf(sqrtf(v4 + (o4 - v4) * vis_beta));
+  running_vis[idx] = now;
+  const float w = vis / fmaxf(now, 1e-12f);
+  weight[i] = w;
+  total_weight[idx] += w;  // indexes are unique (a visible set)
+  row_scale[i] = grad_scale / (vis + vis_smooth);
+}
+
 }  // namespace
+
+extern "C" int gs_optim_visibility_weights(int64_t rows, const int64_t* indexes, const float* visibility,
+                                           float* running_vis, float* total_weight, float vis_beta, float grad_scale,
+                                           float vis_smooth, float* weight, float* row_scale, void* stream) {
+  if (rows == 0) return GS_OK;
+  GS_REQUIRE(indexes && visibility && running_vis && total_weight && weight && row_scale, GS_ERR_INVALID_ARGUMENT,
+             "gs_optim_visibility_weights: NULL buffer");
+  hipLaunchKernelGGL(visibility_weights_kernel, dim3(unsigned(gs_div_up(rows, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), rows, indexes, visibility, running_vis, total_weight, vis_beta,
+                     grad_scale, vis_smooth, weight, row_scale);
+  GS_CHECK_LAUNCH("gs_optim_visibility_weights");
+  return GS_OK;
+}
 
 extern "C" int gs_optim_step(int32_t laprop, int32_t vector_group, int64_t rows, int32_t dims, const int64_t* indexes,
                              const float* weight, float* m, float* v, const float* total_weight, const float* grad,

@@ -141,11 +141,13 @@ class FractionalOpt(torch.optim.Optimizer):
         return views
 
     @torch.no_grad()
-    def _take_step(self, indexes, weight, basis=None, row_scale=None):
+    def _take_step(self, indexes, weight, basis=None, row_scale=None, counted: bool = False):
+        """`counted`: total_weight already includes this step's weights"""
         assert weight.shape == indexes.shape, f"shape mismatch {weight.shape} != {indexes.shape}"
         views = self._rows()
         total_weight = views[0].shared("total_weight")
-        total_weight[indexes] += weight
+        if not counted:
+            total_weight[indexes] += weight
         for view in views:
             if view.grad is not None:
                 update_rows(view, self.algorithm, indexes, weight, total_weight, basis, row_scale)

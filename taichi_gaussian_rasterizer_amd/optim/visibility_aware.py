@@ -11,6 +11,7 @@ from typing import Optional
 
 import torch
 
+from .. import _native as nv
 from .fractional import ADAM, LAPROP, FractionalOpt
 
 
@@ -30,11 +31,18 @@ class VisibilityOptimizer(FractionalOpt):
     @torch.no_grad()
     def step(self, indexes: torch.Tensor, visibility: torch.Tensor, basis: Optional[torch.Tensor] = None):
         assert visibility.shape == indexes.shape, f"shape mismatch {visibility.shape} != {indexes.shape}"
-        running = self._rows()[0].shared("running_vis")
-        current = power_mean_update(running[indexes], visibility, self.vis_beta)
-        running[indexes] = current
-        weight = visibility / current.clamp_min(1e-12)
-        self._take_step(indexes, weight, basis, row_scale=self.grad_scale / (visibility + self.vis_smooth))
+        first = self._rows()[0]
+        running, total_weight = first.shared("running_vis"), first.shared("total_weight")
+        indexes, visibility = indexes.contiguous(), visibility.to(torch.float32).contiguous()
+        nv.require_device(visibility, running, total_weight, what="optimizer step")
+        nv.require_device(indexes, dtype=torch.int64, what="optimizer step indexes")
+        weight, row_scale = torch.empty_like(visibility), torch.empty_like(visibility)
+        # one launch for the whole pacing arithmetic (power_mean_update above states what it computes)
+        nv.check(nv.lib().gs_optim_visibility_weights(
+            indexes.shape[0], nv.ptr(indexes), nv.ptr(visibility), nv.ptr(running), nv.ptr(total_weight),
+            float(self.vis_beta), float(self.grad_scale), float(self.vis_smooth), nv.ptr(weight), nv.ptr(row_scale),
+            nv.stream()), "gs_optim_visibility_weights")
+        self._take_step(indexes, weight, basis, row_scale=row_scale, counted=True)
 
 
 class VisibilityAwareAdam(VisibilityOptimizer):
