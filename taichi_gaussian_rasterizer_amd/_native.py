@@ -99,9 +99,10 @@ class _TimedLib:
     def __init__(self, handle):
         self._h = handle
 
-    def __getattr__(self, name):
+    def __getattr__(self, name):  # first lookup only: the result is stored on the instance
         fn = getattr(self._h, name)
         if name.endswith("_bytes") or name in ("gs_last_error", "gs_version", "gs_grad_row_floats"):
+            setattr(self, name, fn)
             return fn
 
         def call(*args):
@@ -113,6 +114,7 @@ class _TimedLib:
             b.record()
             timer.records.setdefault(name, []).append((a, b))
             return rc
+        setattr(self, name, call)
         return call
 
 
@@ -155,7 +157,17 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
 
+_CONFIGS = {}  # RasterConfig (frozen, hashable) -> its C struct
+
+
 def make_config(config) -> GsRasterConfig:
+    cached = _CONFIGS.get(config)
+    if cached is None:
+        cached = _CONFIGS[config] = _build_config(config)
+    return cached
+
+
+def _build_config(config) -> GsRasterConfig:
     return GsRasterConfig(
         int(config.tile_size), int(config.pixel_stride[0]), int(config.pixel_stride[1]), int(config.antialias),
         int(config.use_alpha_blending), int(config.compute_point_heuristic),
