@@ -74,7 +74,9 @@ class _FusedRender(torch.autograd.Function):
         feats = torch.empty((n, F), **f32)
         indexes = torch.empty((n,), dtype=torch.int64, device=dev)
         slot_of = torch.empty((n,), dtype=torch.int32, device=dev)
-        counts = torch.zeros((8,), dtype=torch.int32, device=dev)  # [0] = V ; [4:8] = K, fullest tile, overflow, heavy tiles
+        # [0] = V (projection) ; [4:8] = K, fullest tile, overflow flag, heavy tiles (mapper scan): every word that is
+        # read is written by a kernel first, so no fill launch
+        counts = torch.empty((8,), dtype=torch.int32, device=dev)
         cam_pos = torch.empty((3,), **f32)
         pbytes = lib.gs_project_scratch_bytes(n)
         pscratch = torch.empty((max(pbytes, 1),), dtype=torch.uint8, device=dev)
