@@ -134,7 +134,7 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  * Fused path (what map_to_tiles runs).  replaces mapper/tile_mapper.py:169-196 as a whole:
  *   gs_map_prepare: OBB tile query per Gaussian (taichi_lib/grid_query.py:10-91) -> per-tile
  *     histogram -> exclusive scan -> tile_ranges (T,2) (empty tiles (0,0), :186) and
- *     counts_out[0] = K, counts_out[1] = largest tile population (device int32[2]).
+ *     counts_out[0] = K, counts_out[1] = largest tile population (device int32[4], see below).
  *   gs_map_finish: re-runs the query, buckets (depth key, index) pairs by tile, then sorts each
  *     tile's bucket on the composite (depth bits, Gaussian index): exactly the order of the
  *     reference's stable 48-bit radix sort of (tile<<32 | depth bits) in generation order
@@ -147,7 +147,8 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  * Asynchronous use (no host read-back between the calls): v may be a capacity with the live count in
  * v_dev (device int32); k_capacity > 0 bounds the pair / overlap buffers -- tiles that would run
  * past it are dropped and counts_out[2] is set to 1 so that the caller can retry with more room;
- * counts_out is int32[4] = {K, fullest tile, overflow flag, 0}; max_tile_count <= 0 in
+ * counts_out is int32[4] = {K, fullest tile, overflow flag, heavy tiles (see gs_raster_fwd; 0 without tile_order)};
+ * max_tile_count <= 0 in
  * gs_map_finish means "not read back": its magnitude is only a hint for sizing the per-tile sort
  * (0 = no hint); fuller tiles are still sorted.  tile_order (optional, T int32) receives the tiles by
  * descending population: a launch order for gs_raster_fwd / gs_raster_bwd (heaviest tiles first).
