@@ -755,14 +755,19 @@ __global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const
     return;
   }
   const uint64_t* seg = pairs + r.x;
-  const int rows = n <= 64 ? 1 : n <= 128 ? 2 : n <= 256 ? 4 : n <= 512 ? 8 : 16;
+  const int rows = (n + 63) >> 6;  // exactly as many register rows as the bucket needs (cost grows with rows^2)
   for (int i = lane; i < rows * 64; i += 64) s_key[i] = i < n ? seg[i] : (0xFFFFFFFF00000000ull | uint64_t(i));
   __syncthreads();
-  if (rows == 1) rank_sort_rows<1>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (rows == 2) rank_sort_rows<2>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (rows == 4) rank_sort_rows<4>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (RMAX >= 8 && rows == 8) rank_sort_rows<(RMAX >= 8 ? 8 : 4)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
-  else if (RMAX >= 16) rank_sort_rows<(RMAX >= 16 ? 16 : 4)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift);
+  switch (rows) {
+    case 1: rank_sort_rows<1>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    case 2: rank_sort_rows<2>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    case 3: rank_sort_rows<3>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    case 4: rank_sort_rows<4>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    case 5: rank_sort_rows<(RMAX >= 8 ? 5 : 1)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    case 6: rank_sort_rows<(RMAX >= 8 ? 6 : 1)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    case 7: rank_sort_rows<(RMAX >= 8 ? 7 : 1)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+    default: rank_sort_rows<(RMAX >= 8 ? 8 : 1)>(s_key, n, lane, r.x, tile, o2p, keys_out, shift); break;
+  }
 }
 
 // ---- reference-shaped primitives ----------------------------------------------------------
