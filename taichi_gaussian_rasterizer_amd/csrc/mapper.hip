@@ -255,19 +255,11 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
   if (i < live_count(a)) {
-    // Gaussians that touch no tile at all (off-screen within the cull margin; above or below this
-    // rank's strip when the frame is sharded) are left out of the ordering, so the counting and
-    // bucketing passes never see them.  The decision is the query itself -- same tests, same result.
+    // Gaussians whose candidate span is empty (off-screen within the cull margin; above or below this rank's
+    // strip when the frame is sharded) are left out of the ordering, so the counting and bucketing passes never
+    // see them.  (A non-empty span whose tiles all fail the OBB test is rare and simply contributes nothing.)
     const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
-    bool any = false;
-    if (q.span_x > 0 && q.span_y > 0) {
-      if (q.span_x * q.span_y > 16) {
-        any = true;  // large candidate set: let the counting pass decide
-      } else {
-        for (int ty = 0; ty < q.span_y && !any; ++ty)
-          for (int tx = 0; tx < q.span_x && !any; ++tx) any = test_tile(q, tx, ty, a.tile_size);
-      }
-    }
+    const bool any = q.span_x > 0 && q.span_y > 0;
     const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
     if (r >= 0) atomicAdd(&s_hist[r], 1);
