@@ -338,12 +338,14 @@ __global__ __launch_bounds__(256) void project_bwd_kernel(BwdArgs a) {
       }
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a.d_position[3 * i + k] = dpos[k];
+    // gradients are written once and read by the optimizer later: keep them out of the caches the next frame's
+    // gathers live in
+    for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(dpos[k], a.d_position + 3 * i + k);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) a.d_log_scaling[3 * i + k] = dls[k];
+    for (int k = 0; k < 3; ++k) __builtin_nontemporal_store(dls[k], a.d_log_scaling + 3 * i + k);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) a.d_rotation[4 * i + k] = dq[k];
-    a.d_alpha_logit[i] = dal;
+    for (int k = 0; k < 4; ++k) __builtin_nontemporal_store(dq[k], a.d_rotation + 4 * i + k);
+    __builtin_nontemporal_store(dal, a.d_alpha_logit + i);
   }
   if (CAMERA) {
     __shared__ float s_part[4][16];

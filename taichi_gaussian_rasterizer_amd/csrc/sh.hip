@@ -258,7 +258,11 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
     for (int k = 0; k < 12; ++k) {
       const int e = k * 64 + lane;           // float4 index inside the 64 x 12 tile
       const int r = e / 12, q = e - r * 12;
-      if (r < rows) dst[e] = *reinterpret_cast<const float4*>(s_tile[wave] + r * TILE_STRIDE + q * 4);
+      if (r < rows) {
+        typedef float vec4 __attribute__((ext_vector_type(4)));
+        const vec4 val = *reinterpret_cast<const vec4*>(s_tile[wave] + r * TILE_STRIDE + q * 4);
+        __builtin_nontemporal_store(val, reinterpret_cast<vec4*>(dst) + e);  // written once, read by the optimizer later
+      }
     }
   }
   if (d_cam && DEG >= 1) {
