@@ -20,8 +20,12 @@ __version__ = "0.1.0"
 def install_as_taichi_splatting():
     """Register this package under the name `taichi_splatting` so that callers written against
     the reference (`from taichi_splatting import render_gaussians`, splat-trainer) import it unchanged."""
+    import importlib
+    import pkgutil
     import sys
     pkg = sys.modules[__name__]
+    for info in pkgutil.walk_packages(pkg.__path__, prefix=__name__ + "."):  # every sub-module under both names
+        importlib.import_module(info.name)
     sys.modules.setdefault("taichi_splatting", pkg)
     for name, mod in list(sys.modules.items()):
         if name.startswith(__name__ + "."):

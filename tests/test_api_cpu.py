@@ -164,3 +164,42 @@ def test_renderer2d_split_helpers_cpu():
     assert off.shape == (50, 2) and torch.isfinite(off).all()
     cov = r2d.point_covariance(g)
     assert torch.allclose(cov, cov.transpose(1, 2), atol=1e-5) and (torch.linalg.eigvalsh(cov) > 0).all()
+
+
+def test_helper_modules_cpu():
+    """torch_lib.transforms / torch_lib.util / misc.indexing / optim.autograd (reference modules of the same names)"""
+    from taichi_gaussian_rasterizer_amd import scenes
+    from taichi_gaussian_rasterizer_amd.misc.indexing import index_features
+    from taichi_gaussian_rasterizer_amd.optim.autograd import restore_grad
+    from taichi_gaussian_rasterizer_amd.torch_lib import transforms, util
+    torch.manual_seed(0)
+    q = torch.nn.functional.normalize(torch.randn(5, 4), dim=1)
+    R = transforms.quat_to_mat(q)
+    assert torch.allclose(R @ R.transpose(1, 2), torch.eye(3).expand(5, 3, 3), atol=1e-5)
+    T = transforms.join_rt(R[0], torch.tensor([1.0, 2.0, 3.0]))
+    r, t = transforms.split_rt(T)
+    assert torch.equal(r, R[0]) and torch.equal(t, torch.tensor([1.0, 2.0, 3.0]))
+    p = torch.randn(7, 3)
+    assert torch.allclose(transforms.transform33(R[0], p), p @ R[0].T, atol=1e-6)
+    assert torch.allclose(transforms.transform44(T, transforms.make_homog(p))[:, :3], p @ R[0].T + t, atol=1e-5)
+    f = torch.randn(6, 2, 3, requires_grad=True)
+    idx = torch.tensor([5, 0, 0, 3])
+    out = index_features(f, idx)
+    assert out.shape == (4, 2, 3)
+    out.sum().backward()
+    assert torch.equal(f.grad[0], torch.full((2, 3), 2.0)) and torch.equal(f.grad[1], torch.zeros(2, 3))
+    g = scenes.random_2d_gaussians(4, (8, 8))
+    assert util.count_nonfinite(g, "g") == {}
+    g.position[1, 0] = float("nan")
+    assert util.count_nonfinite([g, {"x": torch.ones(2)}], "args") == {"args[0].position": 1}
+    try:
+        util.check_finite(g, "g")
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass
+    w = torch.ones(3, requires_grad=True)
+    w.grad = torch.full((3,), 7.0)
+    with restore_grad(w):
+        assert torch.equal(w.grad, torch.zeros(3))
+        w.grad += 1
+    assert torch.equal(w.grad, torch.full((3,), 7.0))
