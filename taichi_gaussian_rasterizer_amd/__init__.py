@@ -25,7 +25,8 @@ def install_as_taichi_splatting():
     import sys
     pkg = sys.modules[__name__]
     for info in pkgutil.walk_packages(pkg.__path__, prefix=__name__ + "."):  # every sub-module under both names
-        importlib.import_module(info.name)
+        if not info.name.rsplit(".", 1)[-1].startswith("lib"):  # libgsplat_hip.so is a C library, not a module
+            importlib.import_module(info.name)
     sys.modules.setdefault("taichi_splatting", pkg)
     for name, mod in list(sys.modules.items()):
         if name.startswith(__name__ + "."):
