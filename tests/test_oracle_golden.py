@@ -90,3 +90,23 @@ def test_det_logf_matches_libm_within_one_ulp():
     ref = np.log(xs[::50].astype(np.float64))
     ulp = np.abs(np.spacing(ref.astype(np.float32)))
     assert (np.abs(got.astype(np.float64) - ref) <= 1.0 * ulp + 1e-45).all()
+
+
+@pytest.mark.parametrize("name,dt,ins,indexes,exp", SH, ids=[c[0] for c in SH])
+def test_torch_lib_sh_matches_reference_vectors(name, dt, ins, indexes, exp):
+    """the package's plain-torch SH utility (torch_lib/spherical_harmonics.py) against the outputs and autograd
+    gradients the reference's own torch oracle produced for the same inputs (tests/golden/sh.npz)"""
+    import torch
+    from taichi_gaussian_rasterizer_amd.torch_lib.spherical_harmonics import evaluate_sh_at
+    tdt = torch.float64 if dt == np.float64 else torch.float32
+    params, points, cam = (torch.tensor(ins[k], dtype=tdt, requires_grad=True) for k in ("params", "points", "camera_pos"))
+    out = evaluate_sh_at(params, points, torch.as_tensor(indexes), cam)
+    out.mean().backward()
+    rtol, atol = (1e-9, 1e-11) if dt == np.float64 else (2e-4, 2e-6)
+    assert np.allclose(out.detach().numpy(), exp["out"], rtol=rtol, atol=atol)
+    assert np.allclose(params.grad.numpy(), exp["grad_params"], rtol=rtol, atol=atol)
+    scale = max(1.0, float(np.abs(exp["grad_points"]).max()))
+    def grad_of(t):  # degree 0 has no view dependence: autograd leaves None, the vectors hold zeros
+        return np.zeros(t.shape, dt) if t.grad is None else t.grad.numpy()
+    assert np.allclose(grad_of(points), exp["grad_points"], rtol=rtol * 10, atol=atol * 10 * scale)
+    assert np.allclose(grad_of(cam), exp["grad_camera_pos"], rtol=rtol * 10, atol=atol * 100 * scale)
