@@ -781,3 +781,29 @@ def test_mapper_and_raster_with_huge_and_tiny_splats():
     gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p_ref, ranges_ref, size, pu.to_np(out.image), gi.numpy(), ocfg)
     pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d", tol=5e-4)
     pu.assert_grad_close(f_t.grad, gf, "grad_features", tol=5e-4)
+
+
+# ------------------------------------------------------------------------------------- determinism
+@pytest.mark.parametrize("n,size,scale,cfg_kw", [(200000, (1024, 768), 2.0, {}), (60000, (512, 384), 6.0, {}),
+                                                 (20000, (256, 192), 6.0, dict(compute_visibility=True))])
+def test_repeated_frames_are_identical(n, size, scale, cfg_kw):
+    """the per-pixel blend order is fixed by the per-tile sort, so the image of a frame does not depend on the arrival
+    order of any atomic: 25 renders of one frame (large grid; crowded tiles; small grid with 8x8 wave regions) are
+    bit-identical, their gradients equal up to float summation order (tools/exp_soak.py runs the long version)"""
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=2, seed=2, scale_factor=scale)
+    cam = camera.to(device=DEV)
+    cfg = RasterConfig(**cfg_kw)
+    a = g.to(DEV).requires_grad_(True)
+    gi = dev(torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(4)))
+    first = None
+    for _ in range(25):
+        for _, t in a.items():
+            t.grad = None
+        r = gs.render_gaussians(a, cam, cfg, use_sh=True)
+        r.image.backward(gi)
+        if first is None:
+            first = (r.image.detach().clone(), r.points_in_view.clone(), {k: t.grad.clone() for k, t in a.items()})
+            continue
+        assert torch.equal(r.image, first[0]) and torch.equal(r.points_in_view, first[1])
+        for k, t in a.items():
+            pu.assert_grad_close(t.grad, first[2][k], f"repeat grad {k}", tol=1e-3)
