@@ -110,3 +110,23 @@ def test_torch_lib_sh_matches_reference_vectors(name, dt, ins, indexes, exp):
         return np.zeros(t.shape, dt) if t.grad is None else t.grad.numpy()
     assert np.allclose(grad_of(points), exp["grad_points"], rtol=rtol * 10, atol=atol * 10 * scale)
     assert np.allclose(grad_of(cam), exp["grad_camera_pos"], rtol=rtol * 10, atol=atol * 100 * scale)
+
+
+@pytest.mark.parametrize("name,dt,ins,exp,meta", [c for c in PROJ if c[1] == np.float64], ids=[c[0] for c in PROJ if c[1] == np.float64])
+def test_torch_lib_projection_matches_reference_vectors(name, dt, ins, exp, meta):
+    """the package's plain-torch EWA projection (torch_lib/projection.py `apply`) against the reference oracle's f64
+    outputs and autograd gradients (tests/golden/projection.npz), at the reference's own bar"""
+    import torch
+    from taichi_gaussian_rasterizer_amd.torch_lib import projection as tp
+    names = ["position", "log_scaling", "rotation", "alpha_logit", "T_camera_world", "projection"]
+    leaves = [torch.tensor(ins[k], dtype=torch.float64, requires_grad=True) for k in names]
+    points, depth, idx = tp.apply(*leaves, tuple(int(v) for v in meta["image_size"]), tuple(meta["depth_range"]),
+                                  blur_cov=float(meta["blur_cov"]))
+    assert idx.shape == exp["indexes"].shape and (idx.numpy() == exp["indexes"]).all()
+    if idx.shape[0] == 0:
+        return
+    (points.mean() + depth.mean()).backward()
+    assert np.allclose(points.detach().numpy(), exp["points"], rtol=1e-5, atol=1e-8)
+    assert np.allclose(depth.detach().numpy(), exp["depth"], rtol=1e-5, atol=1e-8)
+    for leaf, k in zip(leaves, names):
+        assert np.allclose(leaf.grad.numpy(), exp[f"grad_{k}"], rtol=1e-5, atol=1e-8), f"grad {k}"
