@@ -227,6 +227,17 @@ int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const fl
 int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
                          float* grad_features, float* point_heuristic, void* stream);
 
+/* ------------------------------------------------- plain features (render_gaussians(use_sh=False)) --
+ * replaces: `features = gaussians.feature[indexes]` (renderer.py:166) and its index backward, inside the fused frame:
+ * gather rows of the (N, C) features into the rasterizer's feature buffer (row stride out_stride, live count
+ * optionally in v_dev), and the dense adjoint d_features (N, C): row i = gradient row slot_of[i] (stride
+ * grad_out_stride) or zeros for a culled Gaussian.
+ */
+int gs_feature_gather_fwd(int64_t v, const int32_t* v_dev, int32_t channels, const float* features,
+                          const int64_t* indexes, float* out, int32_t out_stride, void* stream);
+int gs_feature_gather_bwd(int64_t n, int32_t channels, const int32_t* slot_of, const float* grad_out,
+                          int32_t grad_out_stride, float* d_features, void* stream);
+
 /* ------------------------------------------------------- depth / depth-variance epilogue --
  * replaces: renderer.py:174-180 compute_depth_variance (+ the feature slice at :213-215) for
  * render_depth=True.  image (P, 2+C) rasterized [z, z^2, features], alpha (P): depth = I0/(alpha+eps),

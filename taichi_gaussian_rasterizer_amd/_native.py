@@ -65,6 +65,8 @@ SIGNATURES = {
     "gs_optim_step": (ctypes.c_int, [_I32, _I32, _I64, _I32, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, c_float,
                                       _I32, _P, _P, _P, _P, _P, _P]),
     "gs_morton_codes64": (ctypes.c_int, [_I64, _P, _P, c_float, _I32, _P, _P]),
+    "gs_feature_gather_fwd": (ctypes.c_int, [_I64, _P, _I32, _P, _P, _P, _I32, _P]),
+    "gs_feature_gather_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _I32, _P, _P]),
     "gs_depth_split_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P]),
     "gs_depth_split_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P, _P]),
 }

@@ -39,7 +39,54 @@ __global__ __launch_bounds__(256) void depth_split_bwd_kernel(int64_t pixels, in
   for (int c = 0; c < C; ++c) out[2 + c] = g_feat ? g_feat[i * C + c] : 0.0f;
 }
 
+// Plain per-Gaussian features (render_gaussians(use_sh=False): `features = gaussians.feature[indexes]`,
+// reference renderer.py:166) gathered into the rasterizer's feature rows, and the dense adjoint: row i of the
+// (N, C) gradient is the rasterizer's gradient row of its slot, or zero when Gaussian i was culled.
+__global__ __launch_bounds__(256) void feature_gather_kernel(int64_t v, const int* v_dev, int C, const float* features,
+                                                             const int64_t* indexes, float* out, int out_stride) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t live = v_dev ? min(int64_t(*v_dev), v) : v;
+  const int64_t row = e / C;
+  if (row >= live) return;
+  const int c = int(e - row * C);
+  out[row * out_stride + c] = features[indexes[row] * C + c];
+}
+
+__global__ __launch_bounds__(256) void feature_scatter_kernel(int64_t n, int C, const int* slot_of, const float* grad,
+                                                              int grad_stride, float* d_features) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t i = e / C;
+  if (i >= n) return;
+  const int c = int(e - i * C);
+  const int slot = slot_of[i];
+  __builtin_nontemporal_store(slot >= 0 ? grad[int64_t(slot) * grad_stride + c] : 0.0f, d_features + e);
+}
+
 }  // namespace
+
+extern "C" int gs_feature_gather_fwd(int64_t v, const int32_t* v_dev, int32_t channels, const float* features,
+                                     const int64_t* indexes, float* out, int32_t out_stride, void* stream) {
+  GS_REQUIRE(channels >= 1, GS_ERR_INVALID_ARGUMENT, "gs_feature_gather_fwd: %d channels", channels);
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(features && indexes && out, GS_ERR_INVALID_ARGUMENT, "gs_feature_gather_fwd: NULL buffer");
+  hipLaunchKernelGGL(feature_gather_kernel, dim3(unsigned(gs_div_up(v * channels, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), v, v_dev, channels, features, indexes, out,
+                     out_stride > 0 ? out_stride : channels);
+  GS_CHECK_LAUNCH("gs_feature_gather_fwd");
+  return GS_OK;
+}
+
+extern "C" int gs_feature_gather_bwd(int64_t n, int32_t channels, const int32_t* slot_of, const float* grad_out,
+                                     int32_t grad_out_stride, float* d_features, void* stream) {
+  GS_REQUIRE(channels >= 1, GS_ERR_INVALID_ARGUMENT, "gs_feature_gather_bwd: %d channels", channels);
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(slot_of && grad_out && d_features, GS_ERR_INVALID_ARGUMENT, "gs_feature_gather_bwd: NULL buffer");
+  hipLaunchKernelGGL(feature_scatter_kernel, dim3(unsigned(gs_div_up(n * channels, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), n, channels, slot_of, grad_out,
+                     grad_out_stride > 0 ? grad_out_stride : channels, d_features);
+  GS_CHECK_LAUNCH("gs_feature_gather_bwd");
+  return GS_OK;
+}
 
 extern "C" int gs_depth_split_fwd(int64_t pixels, int32_t channels, const float* image, const float* alpha,
                                   float eps, float* features, float* depth, float* depth_var, void* stream) {

@@ -57,7 +57,7 @@ class _FusedRender(torch.autograd.Function):
         y0, y1 = (0, full_h) if strip is None else (int(strip[0]), int(strip[1]))
         h = y1 - y0
         C = feature.shape[1]
-        degree = check_sh_degree(feature)
+        degree = check_sh_degree(feature) if feature.dim() == 3 else -1  # -1: plain (N, C) features, no SH
         F = C + (2 if render_depth else 0)
         col0 = F - C
         cfg = nv.make_config(config)
@@ -87,8 +87,12 @@ class _FusedRender(torch.autograd.Function):
                                     nv.ptr(slot_of), nv.ptr(counts), nv.ptr(feats) if render_depth else None, F,
                                     float(y0), nv.ptr(cam_pos), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
         v_dev = nv.ptr(counts)
-        nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
-                               nv.ptr(cam_pos), _off(feats, col0), F, s), "gs_sh_fwd")
+        if degree >= 0:
+            nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
+                                   nv.ptr(cam_pos), _off(feats, col0), F, s), "gs_sh_fwd")
+        else:
+            nv.check(lib.gs_feature_gather_fwd(n, v_dev, C, nv.ptr(feature), nv.ptr(indexes), _off(feats, col0), F, s),
+                     "gs_feature_gather_fwd")
 
         tile_ranges = torch.empty((*tile_shape, 2), dtype=torch.int32, device=dev)
         tile_order = torch.empty((num_tiles,), dtype=torch.int32, device=dev)  # heaviest tiles first
@@ -224,9 +228,13 @@ class _FusedRender(torch.autograd.Function):
             g_pts, g_pts_stride = pp, 7 + col0
 
         d_feature = torch.empty_like(feature)
-        nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
-                               nv.ptr(slot_of), nv.ptr(cam_pos), g_feat, g_feat_stride, _off(feats, col0), F,
-                               nv.ptr(d_feature), None, None, s), "gs_sh_bwd")
+        if m["degree"] >= 0:
+            nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
+                                   nv.ptr(slot_of), nv.ptr(cam_pos), g_feat, g_feat_stride, _off(feats, col0), F,
+                                   nv.ptr(d_feature), None, None, s), "gs_sh_bwd")
+        else:
+            nv.check(lib.gs_feature_gather_bwd(n, C, nv.ptr(slot_of), g_feat, g_feat_stride, nv.ptr(d_feature), s),
+                     "gs_feature_gather_bwd")
         if wait_points is not None:
             wait_points.wait()
 
@@ -250,19 +258,15 @@ class _FusedRender(torch.autograd.Function):
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
-    """The fused node covers the SH-colour frame (the training path).  Anything else -- plain
-    feature gather, median depth, a camera matrix that itself requires grad (its gradient reaches the
-    SH view direction through torch.inverse in the reference) -- runs the composed operators."""
-    if not use_sh or render_median_depth:
-        return False
+    """The fused node covers SH colours (N, C <= 8, D) and plain features (N, C <= 30).  Anything else -- median
+    depth, an empty scene, SH with a camera matrix that itself requires grad (its gradient reaches the view direction
+    through torch.inverse in the reference) -- runs the composed operators."""
     f = gaussians.feature
-    if gaussians.position.shape[0] == 0:
+    if render_median_depth or gaussians.position.shape[0] == 0 or not f.is_cuda or f.dtype != torch.float32:
         return False
-    if f.ndim != 3 or f.shape[1] > 8 or not f.is_cuda or f.dtype != torch.float32:
-        return False
-    if camera_params.T_camera_world.requires_grad:
-        return False
-    return True
+    if use_sh:
+        return f.ndim == 3 and f.shape[1] <= 8 and not camera_params.T_camera_world.requires_grad
+    return f.ndim == 2 and 1 <= f.shape[1] <= 30
 
 
 def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool,

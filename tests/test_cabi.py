@@ -22,7 +22,8 @@ def test_header_declares_the_expected_entry_points():
     names = declared_functions()
     for required in ("gs_project_fwd", "gs_project_bwd", "gs_sh_fwd", "gs_sh_bwd", "gs_map_prepare", "gs_map_finish",
                      "gs_tile_count", "gs_full_cumsum_i32", "gs_tile_emit_keys", "gs_radix_sort_pairs",
-                     "gs_segmented_sort_pairs", "gs_optim_step", "gs_optim_visibility_weights", "gs_morton_codes64",
+                     "gs_segmented_sort_pairs", "gs_optim_step", "gs_optim_visibility_weights", "gs_feature_gather_fwd",
+                     "gs_feature_gather_bwd", "gs_morton_codes64",
                      "gs_find_ranges", "gs_raster_fwd", "gs_raster_bwd", "gs_raster_bwd_unpack", "gs_last_error"):
         assert required in names
 

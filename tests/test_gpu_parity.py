@@ -622,6 +622,42 @@ def test_fused_frame_gradients_through_projected_splats(depth_mode):
     assert a.feature.grad is None or float(a.feature.grad.abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("channels,depth_mode", [(3, False), (6, True), (1, False)])
+def test_fused_frame_plain_features_and_camera_gradients(channels, depth_mode):
+    """render_gaussians(use_sh=False) -- the reference's default -- through the fused node: plain (N, C) features are
+    gathered by gs_feature_gather_fwd, and with no SH in the way the camera matrices may require gradients too"""
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    size, n = (224, 160), 6000
+    cfg = RasterConfig()
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=0, seed=13)
+    feats = torch.rand(n, channels, generator=torch.Generator().manual_seed(8))
+    g = g.replace(feature=feats)
+    gi = dev(torch.rand(size[1], size[0], channels, generator=torch.Generator().manual_seed(3)))
+    grads = []
+    for fused_path in (True, False):
+        cam = camera.to(device=DEV)
+        cam.T_camera_world.requires_grad_(True)
+        cam.projection.requires_grad_(True)
+        a = g.to(DEV).requires_grad_(True)
+        if fused_path:
+            r = gs.render_gaussians(a, cam, cfg, use_sh=False, render_depth=depth_mode)
+        else:
+            g2d, depths, idx, ndc = hip_proj.project_with_ndc(*a.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                              cam.image_size, cam.depth_range, cfg)
+            r = render_projected(idx, g2d, a.feature[idx], depths, cam, cfg, render_depth=depth_mode, ndc_depths=ndc)
+        loss = (r.image * gi).sum()
+        if depth_mode:
+            loss = loss + r.depth.sum()
+        loss.backward()
+        grads.append((r.image.detach().clone(), {k: t.grad.clone() for k, t in a.items()},
+                      cam.T_camera_world.grad.clone(), cam.projection.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0])
+    for k in grads[0][1]:
+        pu.assert_grad_close(grads[0][1][k], grads[1][1][k], f"plain-feature grad {k}", tol=1e-3)
+    pu.assert_grad_close(grads[0][2], grads[1][2], "grad T_camera_world", tol=1e-3)
+    pu.assert_grad_close(grads[0][3], grads[1][3], "grad projection", tol=1e-3)
+
+
 @pytest.mark.parametrize("nb", ["2", "4"])
 def test_fused_frame_splits_heavy_tiles(nb, monkeypatch):
     """the mapper marks the fullest tiles of its launch order (counts_out[3]) and the rasterizer gives each of them
