@@ -45,7 +45,7 @@ class _FusedRender(torch.autograd.Function):
     @staticmethod
     def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                 image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                strip=None, group=None):
+                render_median: bool = False, strip=None, group=None):
         nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                           what="render_gaussians")
         lib = nv.lib()
@@ -152,6 +152,18 @@ class _FusedRender(torch.autograd.Function):
         else:
             img_depth = img_var = torch.empty((0,), **f32)
 
+        # render_median_depth: a second, non-blended forward over the same tile lists that keeps the depth of the splat
+        # taking each pixel past half opacity (reference renderer.py:203-208); no gradient
+        median = torch.empty((0,), **f32)
+        if render_median:
+            from dataclasses import replace as _replace
+            pick = nv.make_config(_replace(config, use_alpha_blending=False, saturate_threshold=0.5,
+                                           compute_visibility=False, compute_point_heuristic=False))
+            median, covered = torch.empty((h, w), **f32), torch.empty((h, w), **f32)
+            nv.check(lib.gs_raster_fwd(n, 1, nv.ptr(points), nv.ptr(depth), nv.ptr(tile_ranges), nv.ptr(o2p),
+                                       o2p.shape[0], w, h, pick, nv.ptr(tile_order), _off(counts, 7), nv.ptr(median),
+                                       nv.ptr(covered), None, s), "gs_raster_fwd")
+
         points_v, depth_v, indexes_v = points[:V], depth[:V], indexes[:V]
         empty = torch.empty((0,), **f32)
         vis_out = vis[:V] if config.compute_visibility else empty
@@ -164,13 +176,14 @@ class _FusedRender(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
                               indexes, cam_pos, tile_ranges, o2p, image, alpha, img_depth, tile_order, counts)
-        ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur)
+        ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur, median)
         if not render_depth:
             ctx.mark_non_differentiable(img_depth, img_var)
-        return out_image, alpha, points_v, depth_v, indexes_v, vis_out, heur, img_depth, img_var
+        return out_image, alpha, points_v, depth_v, indexes_v, vis_out, heur, img_depth, img_var, median
 
     @staticmethod
-    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var):
+    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var,
+                 _g_median=None):
         (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
          tile_ranges, o2p, image, alpha, img_depth, tile_order, counts) = ctx.saved_tensors
         m = ctx.meta
@@ -254,15 +267,15 @@ class _FusedRender(torch.autograd.Function):
                                     g_pts_stride, gd, gd2, gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot),
                                     nv.ptr(d_al), nv.ptr(d_T), nv.ptr(d_proj), nv.ptr(scratch), nbytes, s),
                  "gs_project_bwd")
-        return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None
+        return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None, None
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
-    """The fused node covers SH colours (N, C <= 8, D) and plain features (N, C <= 30).  Anything else -- median
-    depth, an empty scene, SH with a camera matrix that itself requires grad (its gradient reaches the view direction
-    through torch.inverse in the reference) -- runs the composed operators."""
+    """The fused node covers SH colours (N, C <= 8, D) and plain features (N, C <= 30), with or without the depth
+    and median-depth images.  What is left -- an empty scene, SH with a camera matrix that itself requires grad (its
+    gradient reaches the view direction through torch.inverse in the reference) -- runs the composed operators."""
     f = gaussians.feature
-    if render_median_depth or gaussians.position.shape[0] == 0 or not f.is_cuda or f.dtype != torch.float32:
+    if gaussians.position.shape[0] == 0 or not f.is_cuda or f.dtype != torch.float32:
         return False
     if use_sh:
         return f.ndim == 3 and f.shape[1] <= 8 and not camera_params.T_camera_world.requires_grad
@@ -270,20 +283,20 @@ def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth:
 
 
 def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                 strip=None, group=None):
+                 strip=None, group=None, render_median_depth: bool = False):
     """strip=(y0, y1): render only those rows (a multiple-of-tile_size origin); `gaussians2d` of the result
     then holds strip-local means (mean.y - y0).  See parallel.render_gaussians_sharded."""
     from .renderer import Rendering, compute_depth_variance
-    image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var = _FusedRender.apply(
+    image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var, median = _FusedRender.apply(
         gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
         gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
         camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
-        use_depth16, strip, group)
+        use_depth16, render_median_depth, strip, group)
     indexes._gs_unique = True
     if not render_depth:
         img_depth = img_var = None
     return Rendering(image=image, image_weight=alpha, depth=img_depth, depth_var=img_var,
-                     camera=camera_params, config=config,
+                     median_depth=median if render_median_depth else None, camera=camera_params, config=config,
                      point_visibility=vis if config.compute_visibility else None,
                      point_heuristic=heur if config.compute_point_heuristic else None,
                      points_in_view=indexes, point_depth=depths, gaussians2d=g2d)

@@ -1,7 +1,7 @@
 """The 3D renderer entry points and their result record.
 
 `render_gaussians` is what a trainer calls once per view (reference renderer.py:134-171); it runs as the single fused
-frame of fused.py, or -- median depth, SH colours with camera gradients -- as the sequence
+frame of fused.py, or -- SH colours with camera gradients, an empty scene -- as the sequence
 project -> features -> `render_projected` (reference renderer.py:183-231) of this file, every stage a HIP operator.
 `Rendering` carries the images plus the per-splat by-products a trainer prunes and densifies with (reference
 renderer.py:28-131: same field and property names).
@@ -156,7 +156,8 @@ def render_gaussians(gaussians: Gaussians3D, camera_params: CameraParams, config
                                                       render_median_depth=render_median_depth))
     from .fused import fused_supported, render_fused
     if fused_supported(gaussians, camera_params, use_sh, render_median_depth):
-        return render_fused(gaussians, camera_params, config, render_depth, use_depth16)
+        return render_fused(gaussians, camera_params, config, render_depth, use_depth16,
+                            render_median_depth=render_median_depth)
 
     splats, depths, visible, sort_depths = project_with_ndc(
         *gaussians.shape_tensors(), camera_params.T_camera_world, camera_params.projection,

@@ -704,8 +704,8 @@ def test_fused_frame_capacity_overflow_rerun():
 # ----------------------------------------------- remaining render_gaussians options (a15)
 def test_render_gaussians_plain_features_median_depth_depth16_antialias():
     """use_sh=False (feature gather), render_median_depth (second, non-blending raster pass,
-    renderer.py:203-208), use_depth16 keys (tile_mapper.py:47-64) and the antialiased pdf through the
-    composed operators, against the oracle fed the same projected splats."""
+    renderer.py:203-208), use_depth16 keys (tile_mapper.py:47-64) and the antialiased pdf through
+    render_gaussians (the fused frame covers all of them), against the oracle fed the same projected splats."""
     size, n = (160, 112), 4000
     torch.manual_seed(5)
     camera = scenes.benchmark_camera(size)
