@@ -241,10 +241,16 @@ class _FusedRender(torch.autograd.Function):
             g_pts, g_pts_stride = pp, 7 + col0
 
         d_feature = torch.empty_like(feature)
+        # camera matrix under optimisation: the SH view direction depends on the camera centre = inverse(T)[:3, 3]
+        # (reference perspective/params.py:76-78), so the SH adjoint also returns dL/d(centre) and the 4x4 inverse is
+        # differentiated below (pose refinement is rare: a handful of tiny torch ops, off the common path)
+        d_centre = None
+        if m["degree"] >= 1 and ctx.needs_input_grad[5]:
+            d_centre = torch.zeros((3,), dtype=torch.float32, device=dev)
         if m["degree"] >= 0:
             nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
                                    nv.ptr(slot_of), nv.ptr(cam_pos), g_feat, g_feat_stride, _off(feats, col0), F,
-                                   nv.ptr(d_feature), None, None, s), "gs_sh_bwd")
+                                   nv.ptr(d_feature), None, nv.ptr(d_centre), s), "gs_sh_bwd")
         else:
             nv.check(lib.gs_feature_gather_bwd(n, C, nv.ptr(slot_of), g_feat, g_feat_stride, nv.ptr(d_feature), s),
                      "gs_feature_gather_bwd")
@@ -267,18 +273,24 @@ class _FusedRender(torch.autograd.Function):
                                     g_pts_stride, gd, gd2, gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot),
                                     nv.ptr(d_al), nv.ptr(d_T), nv.ptr(d_proj), nv.ptr(scratch), nbytes, s),
                  "gs_project_bwd")
+        if d_centre is not None:  # Y = T^-1, dL/dT = -Y^T (dL/dY) Y^T with dL/dY zero except the centre column
+            with torch.no_grad():
+                Y = torch.linalg.inv(T.detach().cpu().double())
+                dY = torch.zeros((4, 4), dtype=torch.float64)
+                dY[:3, 3] = d_centre.cpu().double()
+                d_T = d_T + (-(Y.T @ dY @ Y.T)).to(device=dev, dtype=torch.float32)
         return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None, None
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
     """The fused node covers SH colours (N, C <= 8, D) and plain features (N, C <= 30), with or without the depth
-    and median-depth images.  What is left -- an empty scene, SH with a camera matrix that itself requires grad (its
-    gradient reaches the view direction through torch.inverse in the reference) -- runs the composed operators."""
+    and median-depth images, camera gradients included.  What is left -- an empty scene, wider features -- runs the
+    composed operators."""
     f = gaussians.feature
     if gaussians.position.shape[0] == 0 or not f.is_cuda or f.dtype != torch.float32:
         return False
     if use_sh:
-        return f.ndim == 3 and f.shape[1] <= 8 and not camera_params.T_camera_world.requires_grad
+        return f.ndim == 3 and f.shape[1] <= 8
     return f.ndim == 2 and 1 <= f.shape[1] <= 30
 
 

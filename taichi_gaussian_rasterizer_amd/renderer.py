@@ -1,7 +1,7 @@
 """The 3D renderer entry points and their result record.
 
 `render_gaussians` is what a trainer calls once per view (reference renderer.py:134-171); it runs as the single fused
-frame of fused.py, or -- SH colours with camera gradients, an empty scene -- as the sequence
+frame of fused.py, or -- an empty scene, more than 30 feature channels -- as the sequence
 project -> features -> `render_projected` (reference renderer.py:183-231) of this file, every stage a HIP operator.
 `Rendering` carries the images plus the per-splat by-products a trainer prunes and densifies with (reference
 renderer.py:28-131: same field and property names).

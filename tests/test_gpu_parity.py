@@ -658,6 +658,41 @@ def test_fused_frame_plain_features_and_camera_gradients(channels, depth_mode):
     pu.assert_grad_close(grads[0][3], grads[1][3], "grad projection", tol=1e-3)
 
 
+def test_fused_frame_sh_with_camera_gradients():
+    """pose refinement: T_camera_world requires grad while the colours are SH -- the view direction depends on the camera
+    centre inverse(T)[:3, 3] (reference perspective/params.py:76-78).  Fused node (SH adjoint returns dL/d centre, the
+    4x4 inverse is differentiated by hand) against the composed operators, where torch differentiates the inverse"""
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    size, n = (200, 144), 5000
+    cfg = RasterConfig()
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=3, seed=17)
+    g = g.replace(feature=g.feature + 0.3 * torch.randn(g.feature.shape, generator=torch.Generator().manual_seed(2)))
+    gi = dev(torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(3)))
+    tilt = torch.eye(4)
+    tilt[:3, :3] = torch.linalg.qr(torch.eye(3) + 0.05 * torch.randn(3, 3, generator=torch.Generator().manual_seed(4))).Q
+    tilt[:3, 3] = torch.tensor([0.02, -0.01, 0.03])
+    out = []
+    for fused_path in (True, False):
+        cam = camera.transformed(tilt).to(device=DEV)
+        cam.T_camera_world.requires_grad_(True)
+        cam.projection.requires_grad_(True)
+        a = g.to(DEV).requires_grad_(True)
+        if fused_path:
+            r = gs.render_gaussians(a, cam, cfg, use_sh=True)
+        else:
+            g2d, depths, idx, ndc = hip_proj.project_with_ndc(*a.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                              cam.image_size, cam.depth_range, cfg)
+            colours = gs.evaluate_sh_at(a.feature, a.position.detach(), idx, cam.camera_position)
+            r = render_projected(idx, g2d, colours, depths, cam, cfg, ndc_depths=ndc)
+        (r.image * gi).sum().backward()
+        out.append((r.image.detach().clone(), cam.T_camera_world.grad.clone(), cam.projection.grad.clone(),
+                    a.feature.grad.clone()))
+    assert torch.allclose(out[0][0], out[1][0], rtol=0, atol=2e-6)   # camera centre: device kernel vs torch inverse
+    pu.assert_grad_close(out[0][1], out[1][1], "grad T_camera_world (projection + SH view direction)", tol=2e-3)
+    pu.assert_grad_close(out[0][2], out[1][2], "grad projection", tol=1e-3)
+    pu.assert_grad_close(out[0][3], out[1][3], "grad feature", tol=1e-3)
+
+
 @pytest.mark.parametrize("nb", ["2", "4"])
 def test_fused_frame_splits_heavy_tiles(nb, monkeypatch):
     """the mapper marks the fullest tiles of its launch order (counts_out[3]) and the rasterizer gives each of them
