@@ -8,7 +8,7 @@ apply, requires_grad_, detach, clone, items, from_tensordict/to_tensordict on pl
 """
 from __future__ import annotations
 
-from dataclasses import dataclass, fields, replace
+from dataclasses import dataclass
 from typing import Tuple
 
 import torch

@@ -298,7 +298,7 @@ def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: b
                  strip=None, group=None, render_median_depth: bool = False):
     """strip=(y0, y1): render only those rows (a multiple-of-tile_size origin); `gaussians2d` of the result
     then holds strip-local means (mean.y - y0).  See parallel.render_gaussians_sharded."""
-    from .renderer import Rendering, compute_depth_variance
+    from .renderer import Rendering
     image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var, median = _FusedRender.apply(
         gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
         gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,

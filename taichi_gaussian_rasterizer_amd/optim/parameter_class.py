@@ -9,7 +9,7 @@ has `.items()`.
 from __future__ import annotations
 
 import copy
-from typing import Callable, Dict, Iterable, Mapping, Optional, Tuple, Union
+from typing import Callable, Dict, Iterable, Optional, Tuple, Union
 
 import torch
 

@@ -21,7 +21,6 @@ with the gloo backend in tests/ (stage callables backed by the CPU oracle there)
 """
 from __future__ import annotations
 
-from dataclasses import replace
 from types import SimpleNamespace
 from typing import Optional, Tuple
 
