@@ -218,7 +218,10 @@ def main():
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu_baseline = run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, args.cpu_frames)
+            check = step()  # one more, untimed frame: its image is compared with the oracle's below
+            gpu_image = (check.image if hasattr(check, "image") else check).detach().float().cpu().numpy()
+            cpu_baseline = run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, args.cpu_frames, gpu_image=gpu_image,
+                                            gpu_overlaps=K)
         except Exception as e:  # the oracle is test infrastructure; its absence must not fail the bench
             cpu_baseline = dict(error=f"{type(e).__name__}: {e}")
 
@@ -255,8 +258,9 @@ def main():
         dist.destroy_process_group()
 
 
-def run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, frames):
-    """The CPU oracle (the C++/OpenMP restatement in oracle/) on the same scene, all host cores."""
+def run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, frames, gpu_image=None, gpu_overlaps=None):
+    """The CPU oracle (the C++/OpenMP restatement in oracle/) on the same scene, all host cores.  Its forward image of
+    the full workload doubles as a parity check of the frame just benchmarked (`parity` in the returned object)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
     import parity_util as pu
@@ -272,12 +276,25 @@ def run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, frames):
     best = None
     for _ in range(max(1, frames)):
         t0 = time.perf_counter()
-        pu.oracle_render(g_cpu, cam_cpu, cfg, use_sh=True, render_depth=wl["depth"], grads=grads)
+        out = pu.oracle_render(g_cpu, cam_cpu, cfg, use_sh=True, render_depth=wl["depth"], grads=grads)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return dict(value=round(W * H / best / 1e6, 3), unit="Mpix/s", cores=orc.num_threads(), kind="port",
-                sample=f"the full workload, best of {max(1, frames)} frames, no warm-up "
-                       f"({best:.2f} s/frame, OpenMP over {orc.num_threads()} threads)")
+    result = dict(value=round(W * H / best / 1e6, 3), unit="Mpix/s", cores=orc.num_threads(), kind="port",
+                  sample=f"the full workload, best of {max(1, frames)} frames, no warm-up "
+                         f"({best:.2f} s/frame, OpenMP over {orc.num_threads()} threads)")
+    if gpu_image is not None and gpu_image.shape == out["image"].shape:
+        diff = np.abs(gpu_image - out["image"])
+        beyond = diff > pu.ATOL + pu.RTOL * np.abs(out["image"])
+        flip_bound = float(cfg.alpha_threshold) * float(np.abs(out["features"]).max())
+        result["parity"] = dict(
+            mean_abs_image_diff=float(diff.mean()), fraction_beyond_2e_5=float(beyond.mean()),
+            max_abs_image_diff=float(diff.max()), single_threshold_flip_bound=flip_bound,
+            overlaps_equal=bool(gpu_overlaps is None or int(out["o2p"].shape[0]) == int(gpu_overlaps)),
+            note="HIP frame vs the oracle's f32 image of the whole workload.  Differences beyond atol = rtol = 2e-5 are "
+                 "single alpha > 1/255 decisions that the device's v_exp_f32 and the host's expf round to different "
+                 "sides; one such flip changes a pixel by at most "
+                 "alpha_threshold * |feature| = single_threshold_flip_bound")
+    return result
 
 
 if __name__ == "__main__":
