@@ -186,3 +186,13 @@ def test_parameter_class_prune_and_split_in_the_fit_loop():
     params, second, _ = epoch(params, 12)
     assert all(torch.isfinite(params[k]).all() for k in params.keys())
     assert second[-1] < first[0], (first, second)
+
+
+def test_fit_image_example_runs_and_improves():
+    """the image-fitting example end to end (synthetic pattern): epochs with pruning and splitting raise the PSNR and
+    grow the population to the target"""
+    from taichi_gaussian_rasterizer_amd.examples import fit_image_gaussians as example
+    history = example.main(["--n", "400", "--target", "900", "--iters", "120", "--epoch", "8", "--max_epoch", "24",
+                            "--size", "160,128"])
+    assert len(history) >= 3 and all(h == h for h in history)
+    assert history[-1] > history[0] + 1.0, history
