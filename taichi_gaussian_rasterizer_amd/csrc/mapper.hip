@@ -141,62 +141,81 @@ __device__ __forceinline__ int block_exclusive_scan(int x, int* s_wave, int& sum
   return before + inc - x;
 }
 
-// Single workgroup: exclusive scan of the T-entry tile histogram (coalesced rounds of 1024 tiles) ->
-// tile_ranges, bucket cursors, K, fullest tile, overflow flag; and, in the same pass, the rasterizer's
+// One workgroup: exclusive scan of the T-entry tile histogram (coalesced rounds of 1024 tiles) ->
+// tile_ranges, bucket cursors, K, fullest tile, overflow flag; beside it a second workgroup builds the rasterizer's
 // launch order: tiles by descending population (counting sort on min(count, 1023); the order inside a
 // bin comes from LDS atomics and is arbitrary -- it only affects scheduling).
 __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
                                                         int* cursors, int* counts_out, int64_t k_capacity,
                                                         int* tile_order) {
+  // workgroup 0: tile ranges, cursors, K / fullest tile / overflow; workgroup 1 (launched only with a tile_order):
+  // the launch order and the heavy-tile count.  Both read the same histogram and neither waits for the other.
   __shared__ int s_wave[16];
   __shared__ int s_bin[1024];
   const int t = threadIdx.x;
+  constexpr int U = 8;  // rounds whose loads are issued together (a load behind every barrier would cost its latency each)
+  if (blockIdx.x == 0) {
+    int carry = 0, mx = 0;
+    for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
+      int cs[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base0 + u * 1024 + t;
+        cs[u] = i < num_tiles ? tile_hist[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = base0 + u * 1024 + t;
+        if (base0 + u * 1024 >= num_tiles) break;  // uniform
+        const int c = cs[u];
+        mx = max(mx, c);
+        int total;
+        const int run = carry + block_exclusive_scan(c, s_wave, total);
+        carry += total;
+        if (i < num_tiles) {
+          // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
+          // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
+          const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
+          tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
+          cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
+        }
+      }
+    }
+    // fullest tile
+    for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
+    if ((t & 63) == 0) s_wave[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+      int m = 0;
+      for (int w = 0; w < 16; ++w) m = max(m, s_wave[w]);
+      counts_out[0] = carry;
+      counts_out[1] = m;
+      counts_out[2] = (k_capacity > 0 && int64_t(carry) > k_capacity) ? 1 : 0;
+      if (!tile_order) counts_out[3] = 0;
+    }
+    return;
+  }
+  // ---- workgroup 1: counting sort of the tiles by descending overlap count (1024 bins, the last one open-ended)
   s_bin[t] = 0;
   __syncthreads();
-  int carry = 0, mx = 0;
-  constexpr int U = 8;  // rounds whose loads are issued together (a load behind every barrier would cost its latency each)
+  int sum = 0;
   for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
     int cs[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = base0 + u * 1024 + t;
-      cs[u] = i < num_tiles ? tile_hist[i] : 0;
+      cs[u] = i < num_tiles ? tile_hist[i] : -1;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base0 + u * 1024 + t;
-      if (base0 + u * 1024 >= num_tiles) break;  // uniform
-      const int c = cs[u];
-      mx = max(mx, c);
-      if (tile_order && i < num_tiles) atomicAdd(&s_bin[min(c, 1023)], 1);
-      int total;
-      const int run = carry + block_exclusive_scan(c, s_wave, total);
-      carry += total;
-      if (i < num_tiles) {
-        // a tile that would run past the caller's pair capacity is dropped (and flagged below): the
-        // caller re-runs with a larger buffer; nothing downstream may index past k_capacity
-        const bool fits = k_capacity <= 0 || int64_t(run) + c <= k_capacity;
-        tile_ranges[i] = (c > 0 && fits) ? make_int2(run, run + c) : make_int2(0, 0);  // tile_mapper.py:186
-        cursors[i] = fits ? run : -(1 << 30);  // negative for the whole launch: any returning add reports it
+    for (int u = 0; u < U; ++u)
+      if (cs[u] >= 0) {
+        sum += cs[u];
+        atomicAdd(&s_bin[min(cs[u], 1023)], 1);
       }
-    }
   }
-  // fullest tile
-  for (int off = 32; off > 0; off >>= 1) mx = max(mx, __shfl_xor(mx, off));
-  if ((t & 63) == 0) s_wave[t >> 6] = mx;
-  __syncthreads();
-  if (t == 0) {
-    int m = 0;
-    for (int w = 0; w < 16; ++w) m = max(m, s_wave[w]);
-    counts_out[0] = carry;
-    counts_out[1] = m;
-    counts_out[2] = (k_capacity > 0 && int64_t(carry) > k_capacity) ? 1 : 0;
-    if (!tile_order) counts_out[3] = 0;
-  }
-  if (!tile_order) return;
-  __syncthreads();
+  int unused, k_total;
+  block_exclusive_scan(sum, s_wave, k_total);
   // start of bin b in descending order = number of tiles in fuller bins: scan the bins from the top
-  int unused;
   const int start = block_exclusive_scan(s_bin[1023 - t], s_wave, unused);
   s_bin[1023 - t] = start;  // read above and written here by the same thread only
   // counts_out[3] = number of "heavy" tiles at the head of the order, which the rasterizer splits into four
@@ -204,11 +223,21 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   // 1.75 n c when the wave has a SIMD to itself), while the whole launch takes about K c / 1024 on 1024 SIMDs:
   // tiles with n > K / 1792 are the ones that bound it.  Large grids (K / 1792 above every tile) split nothing.
   {
-    const int thr_bin = min(max(carry / 1792, 96), 1022);
+    const int thr_bin = min(max(k_total / 1792, 96), 1022);
     if (1023 - t == thr_bin) counts_out[3] = min(start, num_tiles / 4);  // tiles in bins above thr_bin
   }
   __syncthreads();
-  for (int i = t; i < num_tiles; i += 1024) tile_order[atomicAdd(&s_bin[min(tile_hist[i], 1023)], 1)] = i;
+  for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
+    int cs[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = base0 + u * 1024 + t;
+      cs[u] = i < num_tiles ? tile_hist[i] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (cs[u] >= 0) tile_order[atomicAdd(&s_bin[min(cs[u], 1023)], 1)] = base0 + u * 1024 + t;
+  }
 }
 
 // ---- region-binned counting / bucketing --------------------------------------------------
@@ -973,7 +1002,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
                        m.region_start, m.chunk_start, hist);
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
-  hipLaunchKernelGGL(map_scan_kernel, dim3(1), dim3(1024), 0, s, num_tiles, hist,
+  hipLaunchKernelGGL(map_scan_kernel, dim3(tile_order ? 2 : 1), dim3(1024), 0, s, num_tiles, hist,
                      reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity, tile_order);
   GS_CHECK_LAUNCH("gs_map_prepare/scan");
   return GS_OK;
