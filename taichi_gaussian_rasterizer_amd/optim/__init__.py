@@ -7,9 +7,10 @@ and `step(indexes, weight|visibility, basis=None)` signatures; the per-row momen
 kernel (gs_optim_step).  `ParameterClass` (optim/parameter_class.py: parameters + optimizer whose per-row state
 follows pruning and densification) is provided on a plain tensor table instead of tensordict.
 """
+from .autograd import restore_grad
 from .fractional import FractionalAdam, FractionalLaProp, SparseAdam, SparseLaProp
 from .parameter_class import ParameterClass, TensorTable
 from .visibility_aware import VisibilityAwareAdam, VisibilityAwareLaProp
 
 __all__ = ['FractionalAdam', 'FractionalLaProp', 'SparseAdam', 'SparseLaProp', 'VisibilityAwareAdam',
-           'VisibilityAwareLaProp', 'ParameterClass', 'TensorTable']
+           'VisibilityAwareLaProp', 'ParameterClass', 'TensorTable', 'restore_grad']

@@ -85,3 +85,30 @@ def test_parameter_class_state_follows_rows():
     again = ParameterClass.from_state_dict(grown.state_dict(), optimizer=torch.optim.Adam, betas=(0.9, 0.99))
     assert torch.equal(again.position, grown.position) and again.learning_rates == grown.learning_rates
     assert torch.equal(again.tensor_state["position"]["exp_avg"], grown.tensor_state["position"]["exp_avg"])
+
+
+def test_reference_named_optim_modules_import_and_refuse_host_tensors():
+    """optim/fractional_adam.py, fractional_laprop.py, util.py, autograd.py exist under the reference's names; the kernel
+    callables are HIP launches and refuse host tensors (no CPU fallback)"""
+    import torch
+    from taichi_gaussian_rasterizer_amd import optim
+    from taichi_gaussian_rasterizer_amd.optim import fractional_adam, fractional_laprop, util
+    assert callable(optim.restore_grad)
+    p = torch.zeros(6, 3, requires_grad=True)
+    p.grad = torch.ones(6, 3)
+    state = {}
+    m, v = util.get_vector_state(state, p)
+    assert m.shape == (6, 3) and v.shape == (6,)
+    assert util.get_scalar_state({}, p)[1].shape == (6, 3)
+    assert util.get_total_weight(state, 6, p.device).shape == (6,) and "total_weight" in state
+    assert util.get_running_vis(state, (6,), p.device).dtype == torch.float32
+    flat, g = util.flatten_param(p)
+    assert flat.shape == g.shape == (6, 3)
+    for module in (fractional_adam, fractional_laprop):
+        kernel = module.vector_kernel(dims=3)
+        assert kernel is module.vector_kernel(dims=3)  # cached per option set, like the reference's @cache
+        with pytest.raises(Exception):
+            kernel(torch.zeros(2, 3), torch.tensor([0, 1]), torch.ones(2), m, v, state["total_weight"], p.grad, 0.1)
+    with optim.restore_grad(p):
+        assert float(p.grad.abs().sum()) == 0.0
+    assert float(p.grad.sum()) == 18.0

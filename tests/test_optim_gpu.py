@@ -196,3 +196,37 @@ def test_fit_image_example_runs_and_improves():
                             "--size", "160,128"])
     assert len(history) >= 3 and all(h == h for h in history)
     assert history[-1] > history[0] + 1.0, history
+
+
+@pytest.mark.parametrize("kind", ["adam", "laprop"])
+@pytest.mark.parametrize("vector", [False, True])
+def test_reference_named_kernel_factories(kind, vector):
+    """optim/fractional_adam.py / fractional_laprop.py `scalar_kernel` / `vector_kernel`: the callable with the
+    reference's argument list (optim/fractional.py:118-131) against the restatement of its arithmetic"""
+    import importlib
+    from optim_reference import moment_step
+    module = importlib.import_module(f"taichi_gaussian_rasterizer_amd.optim.fractional_{kind}")
+    from taichi_gaussian_rasterizer_amd.optim import util
+    gen = torch.Generator().manual_seed(3)
+    n, d, rows = 500, 3, 200
+    param = torch.randn(n, d, generator=gen).cuda()
+    grad = torch.randn(n, d, generator=gen).cuda()
+    idx = torch.randperm(n, generator=gen)[:rows].sort().values.cuda()
+    state = {}
+    m, v = (util.get_vector_state if vector else util.get_scalar_state)(state, param)
+    total = util.get_total_weight(state, n, param.device)
+    assert v.shape == ((n,) if vector else (n, d)) and total.shape == (n,)
+    betas, eps, lr = (0.8, 0.95), 1e-12, 0.05
+    kernel = (module.vector_kernel(betas=betas, eps=eps, dims=d) if vector else module.scalar_kernel(betas=betas, eps=eps))
+    m_ref, v_ref = m.cpu().double(), v.cpu().double()
+    for it in range(3):
+        w = torch.rand(rows, generator=gen) * 1.5
+        total[idx] += w.cuda()
+        step = param.new_zeros(rows, d)
+        kernel(step, idx, w.cuda(), m, v, total, grad, lr)
+        want = moment_step(kind, vector, idx.cpu(), w.double(), m_ref, v_ref, total.cpu().double(), grad.cpu().double(),
+                           lr, betas, eps)
+        assert torch.allclose(step.cpu().double(), want, rtol=2e-5, atol=1e-7), f"step {it}"
+        assert torch.allclose(m.cpu().double(), m_ref, rtol=2e-5, atol=1e-7)
+        assert torch.allclose(v.cpu().double(), v_ref, rtol=2e-5, atol=1e-7)
+        grad = torch.randn(n, d, generator=gen).cuda()
