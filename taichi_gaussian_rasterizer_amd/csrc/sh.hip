@@ -74,7 +74,8 @@ __device__ __forceinline__ void load_row(const float* row, float* out) {
   }
 }
 
-template <int DEG>
+// CT: channel count known at compile time (3: all loads of a Gaussian's rows are issued before the first use), 0: run-time C
+template <int DEG, int CT>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev, int C, const float* params,
                                                      const float* positions, const int64_t* indexes,
                                                      const float* cam, float* out, int out_stride) {
@@ -83,6 +84,23 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev
   if (v_dev != nullptr && i >= *v_dev) return;
   if (i >= v) return;
   const int64_t idx = indexes[i];
+  if (CT > 0) {
+    float rows[CT > 0 ? CT : 1][D];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) load_row<D>(params + (idx * CT + c) * D, rows[c]);
+    const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1], dz = positions[3 * idx + 2] - cam[2];
+    const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
+    float Y[D];
+    rsh<DEG>(dx / nrm, dy / nrm, dz / nrm, Y);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      float acc = 0.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) acc += Y[d] * rows[c][d];
+      out[i * out_stride + c] = fminf(fmaxf(acc + 0.5f, 0.0f), 1.0f);
+    }
+    return;
+  }
   const float dx = positions[3 * idx] - cam[0], dy = positions[3 * idx + 1] - cam[1], dz = positions[3 * idx + 2] - cam[2];
   const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
   float Y[D];
@@ -291,9 +309,12 @@ extern "C" int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int3
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_stride <= 0) out_stride = channels;
   const dim3 grid(unsigned(gs_div_up(v, 256))), block(256);
-#define SH_FWD(DEG)                                                                                               \
-  hipLaunchKernelGGL(sh_fwd_kernel<DEG>, grid, block, 0, s, v, v_dev, channels, params, positions, indexes,       \
+#define SH_FWD_C(DEG, CT)                                                                                         \
+  hipLaunchKernelGGL((sh_fwd_kernel<DEG, CT>), grid, block, 0, s, v, v_dev, channels, params, positions, indexes, \
                      camera_pos, out, out_stride)
+#define SH_FWD(DEG)                                                                                               \
+  if (channels == 3) SH_FWD_C(DEG, 3);                                                                            \
+  else SH_FWD_C(DEG, 0)
   switch (degree) {
     case 0: SH_FWD(0); break;
     case 1: SH_FWD(1); break;

@@ -1,0 +1,10 @@
+#!/bin/bash
+# as ab_lib.sh, printing one named stage:  tools/ab_stage.sh STAGE lib_a.so lib_b.so ...
+stage=$1; shift
+for round in 1 2 3; do
+  for lib in "$@"; do
+    GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 2>/dev/null | python3 -c "
+import sys, json; d = json.loads(sys.stdin.read()); s = d['stages_ms']
+print('$lib', d['ms_per_step'], '$stage', s.get('$stage'))"
+  done
+done
