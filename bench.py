@@ -53,9 +53,40 @@ def algorithmic_bytes(N, V, K, T, P, F, C, D):
         "gs_raster_fwd": 8 * T + K * (4 + 28 + 4 * F) + 4 * P * (F + 1),
         "gs_raster_bwd": 8 * T + K * (4 + 28 + 4 * F) + 8 * P * F + 4 * (7 + F) * K,
         "gs_raster_bwd_unpack": V * (64 + 4 * (7 + F)),
-        "gs_sh_bwd": V * (8 + 12 + 4 * C * D + 4 * C) + 2 * 4 * C * D * N,
+        # dense adjoint: one 4CD-byte row written per Gaussian (zeros for culled ones), per visible Gaussian its
+        # position, the forward colour (clamp mask) and the 64-B gradient row are read; coefficients are not re-read
+        "gs_sh_bwd": 4 * C * D * N + 4 * N + V * (12 + 4 * C + 64),
         "gs_project_bwd": 44 * N + 4 * N + 32 * V + 44 * N,
     }
+
+
+def survey_bytes(N, V, K, T, P, F, C, D, backward, kb=8):
+    """SURVEY.md 8(d) whole-frame formula (B_fwd, B_bwd), general feature width F."""
+    b_fwd = (44 * N + V * (40 + (20 + 4 * C * D + 4 * C) + 8 + 32 + 8 + 36)
+             + K * ((kb + 4) + 2 * (kb + 4) + kb + (32 + 4 * F)) + 16 * T + 4 * P * (F + 1))
+    b_bwd = (8 * T + K * (32 + 4 * F) + 8 * P * F + 4 * (7 + F) * K + 4 * (7 + F) * V
+             + V * (20 + 4 * C * D + 4 * C) + 4 * C * D * N + 76 * V + 44 * N)
+    return b_fwd, (b_bwd if backward else 0)
+
+
+def launch_command(args, port=None):
+    """The one-node multi-rank launch of this script: one process per GPU over RCCL (torch.distributed.run)."""
+    import socket
+    if port is None:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--workload", args.workload, "--cpu-frames", str(args.cpu_frames)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    if args.no_kernel_timing:
+        cmd.append("--no-kernel-timing")
+    if args.interleave:
+        cmd += ["--interleave", str(args.interleave)]
+    return cmd
 
 
 def main():
@@ -67,7 +98,27 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--interleave", type=int, default=0,
+                    help="N > 1: tile rows per band of the interleaved strip assignment (0 = one contiguous strip)")
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print the multi-rank launch command for --gpus N and exit")
     args = ap.parse_args()
+
+    # --gpus N without a launcher around us: start the N ranks ourselves, as a CHILD process (never exec: this
+    # process may already hold the GPU), relay its output and exit with its code.  No GPU call happens before this.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import subprocess
+        cmd = launch_command(args)
+        if args.dry_run_launch:
+            print(" ".join(cmd))
+            return 0
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("MASTER_ADDR", "127.0.0.1")
+        return subprocess.run(cmd, env=env).returncode
+    if args.dry_run_launch:
+        print("single process: " + " ".join([sys.executable, os.path.abspath(__file__), "--gpus", "1"]))
+        return 0
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -77,6 +128,15 @@ def main():
     backend = os.environ.get("GS_BENCH_BACKEND", "nccl")
     if os.environ.get("GS_BENCH_SHARE_GPU") == "1":
         local_rank = 0
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a mislabelled line",
+              file=sys.stderr)
+        return 2
+    share = os.environ.get("GS_BENCH_SHARE_GPU") == "1"
+    if not share and torch.cuda.device_count() < world:  # device_count() does not initialise the GPU
+        print(f"bench.py: --gpus {world} needs {world} GPUs, this host shows {torch.cuda.device_count()}",
+              file=sys.stderr)
+        return 3
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path in the product"
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
@@ -110,20 +170,24 @@ def main():
             for _, t in g.items():
                 t.grad = None
         if world > 1:
-            r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=wl["depth"])
-            y0, y1 = r.strip
+            r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=wl["depth"],
+                                                  interleave=args.interleave)
         else:
             r = gs.render_gaussians(g, cam, cfg, use_sh=True, render_depth=wl["depth"])
-            y0, y1 = 0, H
         info["V"] = int(r.points_in_view.shape[0])
         if not wl["backward"]:
             return r
         # backward from a fixed random dL/d(outputs): the loss function is the caller's, not part of the path
         # (the reference benchmark uses image.sum(), i.e. an all-ones gradient: benchmarks/bench_rasterizer.py:83-85)
+        if world > 1 and "rows" not in info:  # this rank's rows of the upstream gradients, gathered once
+            rows = parallel.owned_pixel_rows(r.bands).to(dev)
+            info["rows"] = rows
+            info["G"] = [t[rows].contiguous() for t in (G, Gd, Gv) if t is not None]
+        Gs = info["G"] if world > 1 else [t for t in (G, Gd, Gv) if t is not None]
         if wl["depth"]:
-            torch.autograd.backward([r.image, r.depth, r.depth_var], [G[y0:y1], Gd[y0:y1], Gv[y0:y1]])
+            torch.autograd.backward([r.image, r.depth, r.depth_var], Gs)
         else:
-            r.image.backward(G[y0:y1])
+            r.image.backward(Gs[0])
         return r
 
     def sync():
@@ -159,10 +223,25 @@ def main():
             step()
         sync()
         nv.timer.enabled = False
+    allreduce = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if wl["backward"]:
+            # the frame's one exchange step on its own: 4*(7+F) bytes per visible Gaussian, summed over the ranks
+            F_ = 5 if wl["depth"] else 3
+            buf = torch.zeros((info["V"], 7 + F_), dtype=torch.float32, device=dev)
+            for _ in range(3):
+                dist.all_reduce(buf)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                dist.all_reduce(buf)
+            sync()
+            allreduce = dict(bytes=int(buf.numel() * 4), ms=round((time.perf_counter() - t1) * 100, 4),
+                             note="gradient all-reduce timed alone, 10 back-to-back calls (inside a frame it overlaps "
+                                  "the SH adjoint)")
     ms_per_step = 1e3 * elapsed / args.steps
 
     # ---- scene statistics for the byte formulas (untimed)
@@ -214,6 +293,7 @@ def main():
                 except Exception:
                     pass
     whole = sum(v for k, v in by.items() if wl["backward"] or not k.endswith(("_bwd", "_unpack")))
+    sv = survey_bytes(wl["n"], V, K, T, W * H, F, 3, D, wl["backward"])
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -232,6 +312,9 @@ def main():
             "value": round(W * H / (ms_per_step * 1e-3) / 1e6, 2),
             "unit": "Mpix/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1,
+            "collective_backend": (dist.get_backend() if world > 1 else None),
+            "allreduce": allreduce,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -250,7 +333,11 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "whole_path": {"algorithmic_bytes_per_frame": int(whole),
-                           "hbm_frac": round(whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                           "hbm_frac": round(whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                           "survey_8d_bytes_per_frame": int(sum(sv)),
+                           "survey_8d_hbm_frac": round(sum(sv) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                           "note": "first pair: sum of the per-stage byte table above (what this implementation's "
+                                   "stages must move); second pair: SURVEY.md 8(d) B_fwd + B_bwd on the measured V, K"},
             "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items()) if "ms_per_step" in v},
         }
         print(json.dumps(out), flush=True)
@@ -298,4 +385,4 @@ def run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, frames, gpu_image=None, gpu_overla
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

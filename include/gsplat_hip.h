@@ -51,7 +51,32 @@ typedef struct GsRasterConfig {
   float clamp_max_alpha;
   float alpha_threshold;
   float saturate_threshold;
+  /* Not a reference field.  The reference's forward keeps blending down a tile's whole list (forward.py:84-128);
+   * this library stops a 16x16 region once EVERY pixel of it has less than forward_cut of its transmittance left.
+   * What is dropped changes a pixel by less than forward_cut * max|feature|.  0 reproduces the reference literally
+   * (the walk then ends only where f32 transmittance is exactly zero, i.e. where every further weight is 0.0f).
+   * The Python layer passes RasterConfig.forward_cut (default 2^-20), divided by the squared far plane when the
+   * z / z^2 depth features are blended, so the bound is relative to the feature magnitude. */
+  float forward_cut;
+  /* Developer tuning aids, per call (the library reads no environment variable and keeps no global state); results
+   * never depend on them.  tune_wave_sub_blocks: 0 = choose the rasterizer's wave region from the grid size, 1 | 2 | 4
+   * = force 8x8 / 16x8 / 16x16 pixels per wave.  tune_no_heavy_split: 1 = never give the fullest tiles four
+   * workgroups. */
+  int32_t tune_wave_sub_blocks;
+  int32_t tune_no_heavy_split;
 } GsRasterConfig;
+
+/* Screen-tile sharding (the reference has no counterpart): which tile ROWS of the full image one call
+ * covers.  Row ty is owned iff row_begin <= ty < row_end and (period <= 1 or (ty / band) % period == phase);
+ * owned rows keep their order and are numbered 0, 1, ... ("local rows").  period <= 1: one contiguous strip;
+ * period > 1 (with row_begin = 0, row_end = all rows): bands of `band` rows dealt round-robin to `period` owners
+ * (interleaved strips, load balance on real scenes).  With a shard, `height` stays the FULL image height, splat
+ * coordinates stay full-image coordinates, tile ids / tile_ranges / tile_order are local (local row * tiles_wide +
+ * column) and image buffers hold the owned pixel rows only, in order.  NULL = the whole image. */
+typedef struct GsRowShard {
+  int32_t row_begin, row_end;
+  int32_t band, period, phase;
+} GsRowShard;
 
 const char* gs_last_error(void);
 int gs_version(void);
@@ -70,8 +95,6 @@ int gs_version(void);
  *   indexes: (V) int64 ascending; slot_of: (n) int32, compact row of Gaussian i or -1.
  *   depth_features (optional): row i of a (V, depth_features_stride) raster-feature buffer receives
  *   [z, z^2] in its first two columns (renderer.py:191-193, render_depth=True).
- *   mean_y_offset is subtracted from the projected mean.y as it is written (0 for a whole image; the
- *   origin row of a tile-row strip when the frame is sharded over GPUs -- culling still uses the full image).
  *   camera_pos (optional, 3 floats): receives the camera centre, as gs_camera_position would (saves its launch).
  * scratch: gs_project_scratch_bytes(n).
  */
@@ -80,7 +103,7 @@ int gs_project_fwd(int64_t n, const float* position, const float* log_scaling, c
                    const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
                    int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
                    float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
-                   float* depth_features, int32_t depth_features_stride, float mean_y_offset, float* camera_pos,
+                   float* depth_features, int32_t depth_features_stride, float* camera_pos,
                    void* scratch, int64_t scratch_bytes, void* stream);
 
 /* replaces: perspective/projection.py:84-118 indexed_project_kernel.grad (Taichi autodiff,
@@ -152,15 +175,19 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  * gs_map_finish means "not read back": its magnitude is only a hint for sizing the per-tile sort
  * (0 = no hint); fuller tiles are still sorted.  tile_order (optional, T int32) receives the tiles by
  * descending population: a launch order for gs_raster_fwd / gs_raster_bwd (heaviest tiles first).
+ * shard (optional, host pointer, read during the call): only the owned tile rows are mapped; num_tiles in
+ * gs_map_scratch_bytes and the T of tile_ranges / tile_order are then the LOCAL tile count, sorted_keys carry local
+ * tile ids.  Tile decisions are computed in full-image coordinates: the tiles of a shard get exactly the lists the
+ * unsharded call gives them.
  */
 int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
-                   int32_t* tile_order, void* scratch, int64_t scratch_bytes, void* stream);
+                   int32_t* tile_order, const GsRowShard* shard, void* scratch, int64_t scratch_bytes, void* stream);
 int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_count, const float* points,
                   const float* depth, int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
                   const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys, void* pair_scratch,
-                  void* scratch, int64_t scratch_bytes, void* stream);
+                  const GsRowShard* shard, void* scratch, int64_t scratch_bytes, void* stream);
 
 /* Reference-shaped primitives (the same pipeline stage by stage, as the reference runs it). */
 
@@ -205,11 +232,12 @@ int gs_find_ranges(int64_t k, const uint64_t* sorted_keys, int32_t use_depth16, 
  * NULL = XCD-contiguous bands.  heavy_tiles (optional, device int32, from gs_map_prepare's counts_out[3]): the
  * first *heavy_tiles tiles of the order are rasterized by four workgroups each (one per 8x8 quadrant; tile_size
  * 16 only, ignored otherwise) so that no single wave walks a very full tile alone.  Results depend on neither.
+ * shard (optional, see GsRowShard): tile ids are local, image / alpha hold the owned pixel rows only.
  */
 int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
                   const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
                   int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const int32_t* heavy_tiles,
-                  float* image, float* alpha, float* visibility, void* stream);
+                  float* image, float* alpha, float* visibility, const GsRowShard* shard, void* stream);
 
 /* replaces: rasterizer/backward.py:53-228 _backward_kernel.
  * Per-Gaussian gradients are accumulated with float atomics into ONE row per Gaussian,
@@ -223,7 +251,8 @@ int32_t gs_grad_row_floats(int32_t num_features);
 int gs_raster_bwd(int64_t v, int32_t num_features, const float* points, const float* features,
                   const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
                   int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order, const int32_t* heavy_tiles,
-                  const float* image, const float* grad_image, float* grad_rows, void* stream);
+                  const float* image, const float* grad_image, float* grad_rows, const GsRowShard* shard,
+                  void* stream);
 int gs_raster_bwd_unpack(int64_t v, int32_t num_features, const float* grad_rows, float* grad_points,
                          float* grad_features, float* point_heuristic, void* stream);
 

@@ -712,6 +712,34 @@ extern "C" {
 ORC_PROJECT(f32, float)
 ORC_PROJECT(f64, double)
 
+// Diagnostic for the parity tests (not a reference function): per pixel, how close the forward walk of
+// rasterizer/forward.py:84-128 comes to flipping one of its `alpha > alpha_threshold` decisions --
+// margin[pixel] = min over the tile's splats of |alpha_p * pdf - thr| / thr, evaluated in f32 exactly as raster_fwd
+// does.  A pixel on which two correct f32 implementations disagree by more than rounding must have a tiny margin:
+// the only discontinuity of the forward is that comparison, and one flip moves the pixel by <= thr * |feature|.
+void orc_raster_flip_margin_f32(const float* points, const int32_t* ranges, const int32_t* o2p, int W, int H,
+                                const RasterCfg* cfg, float* margin) {
+  const int ts = cfg->tile_size;
+  const int tw = (W + ts - 1) / ts, th = (H + ts - 1) / ts;
+  const float thr = float(cfg->alpha_threshold);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int tile = 0; tile < tw * th; ++tile) {
+    const int tx0 = (tile % tw) * ts, ty0 = (tile / tw) * ts;
+    const int start = ranges[2 * tile], end = ranges[2 * tile + 1];
+    for (int py = ty0; py < std::min(ty0 + ts, H); ++py)
+      for (int px = tx0; px < std::min(tx0 + ts, W); ++px) {
+        const float pxf = float(px) + 0.5f, pyf = float(py) + 0.5f;
+        float best = 1e30f;
+        for (int k = start; k < end; ++k) {
+          const float* g = points + int64_t(o2p[k]) * 7;
+          const float a = g[6] * (cfg->antialias ? pdf_aa<float>(pxf, pyf, g) : pdf_plain<float>(pxf, pyf, g));
+          best = std::min(best, std::fabs(a - thr) / thr);
+        }
+        margin[int64_t(py) * W + px] = best;
+      }
+  }
+}
+
 // ndc depth with the fixed f32 operation order of SURVEY 8a-3 (torch_lib/projection.py:120-123).
 void orc_ndc_depth_f32(int64_t n, const float* depth, double near_p, double far_p, float* out) {
   const float inv_far = float(1.0 / far_p);

@@ -68,9 +68,11 @@ def main():
     ref = load_reference_torch_lib()
 
     proj = {}
-    for seed in range(4):
-        for n in (1, 17, 200):
-            for blur in (0.0, 0.3):
+    # seeds 0..7, n in {1, 17, 1000} (+ the 200-point cases of round 1); the 1000-point scenes with the
+    # default blur only, to keep the fixture at a few MB
+    for seed in range(8):
+        for n in (1, 17, 200, 1000):
+            for blur in ((0.3,) if n == 1000 else (0.0, 0.3)):
                 for dtype, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
                     case = projection_case(ref, seed, n, blur, dtype)
                     key = f"s{seed}_n{n}_b{int(blur * 10)}_{tag}"

@@ -239,7 +239,12 @@ def map_to_tiles(gaussians2d, depth, image_size, config=OracleConfig(), use_dept
     vals = np.empty((total,), np.int32)
     lib().orc_tile_emit(_i64(g.shape[0]), _p(g), _p(d), _p(cum), Wp, Hp, ts, ctypes.c_double(cfg.alpha_threshold),
                         int(use_depth16), _p(keys), _p(vals))
-    keys, vals = radix_sort_pairs(keys, vals, 0, 32 if use_depth16 else 48 if tile_shape[0] * tile_shape[1] < 65535 else 64)
+    # reference: 48 bits (32 of depth + 16 of tile id), or 32 with 16-bit depth codes, and at most 65534 tiles
+    # (tile_mapper.py:29,154,175).  Past that limit -- which the build lifts -- the tile id simply takes the bits it
+    # needs above the depth field: key = tile << (16 | 32) | depth code, as a u64.
+    num_tiles = tile_shape[0] * tile_shape[1]
+    tile_bits = 16 if num_tiles < 65535 else max(1, (num_tiles - 1).bit_length())
+    keys, vals = radix_sort_pairs(keys, vals, 0, (16 if use_depth16 else 32) + tile_bits)
     lib().orc_tile_ranges(_i64(total), _p(keys), int(use_depth16), _i64(tile_shape[0] * tile_shape[1]), _p(ranges))
     return (vals, ranges, keys) if return_keys else (vals, ranges)
 
@@ -283,6 +288,20 @@ def rasterize_backward(gaussians2d, features, overlap_to_point, tile_overlap_ran
     getattr(lib(), f"orc_raster_bwd_{s}")(_i64(V), F, _p(g), _p(f), _p(rng), _p(o2p), _i64(o2p.shape[0]), W, H,
                                           ctypes.byref(c), _p(im), _p(gi), _p(gg), _p(gf), _p(heur))
     return gg, gf, (heur if cfg.compute_point_heuristic else None)
+
+
+def raster_flip_margin(gaussians2d, overlap_to_point, tile_overlap_ranges, image_size, config=OracleConfig()):
+    """(H, W) f32: per pixel, min over its tile's splats of |alpha - alpha_threshold| / alpha_threshold (diagnostic
+    used by the parity tests to prove that an out-of-tolerance pixel is an `alpha > threshold` decision two f32
+    implementations round to different sides, forward.py:100)."""
+    cfg = OracleConfig.of(config)
+    g = _np(gaussians2d, np.float32)
+    o2p, rng = _np(overlap_to_point, np.int32), _np(tile_overlap_ranges, np.int32).reshape(-1, 2)
+    W, H = int(image_size[0]), int(image_size[1])
+    margin = np.empty((H, W), np.float32)
+    c = cfg.c_struct()
+    lib().orc_raster_flip_margin_f32(_p(g), _p(rng), _p(o2p), W, H, ctypes.byref(c), _p(margin))
+    return margin
 
 
 def rasterize(gaussians2d, depth, features, image_size, config=OracleConfig(), use_depth16=False):

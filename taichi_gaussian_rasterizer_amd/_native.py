@@ -24,10 +24,24 @@ class GsRasterConfig(ctypes.Structure):
     _fields_ = [("tile_size", c_int32), ("pixel_stride_x", c_int32), ("pixel_stride_y", c_int32),
                 ("antialias", c_int32), ("use_alpha_blending", c_int32), ("compute_point_heuristic", c_int32),
                 ("compute_visibility", c_int32), ("clamp_margin", c_float), ("blur_cov", c_float),
-                ("clamp_max_alpha", c_float), ("alpha_threshold", c_float), ("saturate_threshold", c_float)]
+                ("clamp_max_alpha", c_float), ("alpha_threshold", c_float), ("saturate_threshold", c_float),
+                ("forward_cut", c_float), ("tune_wave_sub_blocks", c_int32), ("tune_no_heavy_split", c_int32)]
+
+
+class GsRowShard(ctypes.Structure):
+    """include/gsplat_hip.h GsRowShard: the tile rows of the full image one call covers."""
+    _fields_ = [("row_begin", c_int32), ("row_end", c_int32), ("band", c_int32), ("period", c_int32),
+                ("phase", c_int32)]
+
+
+# Developer tuning aids (tools/exp_*.py, the wave-region tests): passed per call inside GsRasterConfig; the
+# library itself reads no environment variable.  GS_RASTER_NB / GS_RASTER_HEAVY seed them at import.
+TUNING = {"wave_sub_blocks": int(os.environ.get("GS_RASTER_NB", "0") or 0),
+          "no_heavy_split": 1 if os.environ.get("GS_RASTER_HEAVY", "1") == "0" else 0}
 
 
 _CFG = POINTER(GsRasterConfig)
+_SHARD = POINTER(GsRowShard)
 _P = c_void_p
 _I32, _I64, _F64 = c_int32, c_int64, c_double
 
@@ -37,7 +51,7 @@ SIGNATURES = {
     "gs_version": (ctypes.c_int, []),
     "gs_project_scratch_bytes": (_I64, [_I64]),
     "gs_project_fwd": (ctypes.c_int, [_I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _F64, _F64, _CFG, _P, _P, _P, _P, _P,
-                                       _P, _P, _I32, c_float, _P, _P, _I64, _P]),
+                                       _P, _P, _I32, _P, _P, _I64, _P]),
     "gs_project_bwd_scratch_bytes": (_I64, [_I64]),
     "gs_project_bwd": (ctypes.c_int, [_I64, _I64, _P, _P, _P, _P, _P, _P, _I32, _I32, _CFG, _P, _P, _I32, _P, _P,
                                        _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
@@ -46,9 +60,9 @@ SIGNATURES = {
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
                                   _P]),
     "gs_map_scratch_bytes": (_I64, [_I64, _I64]),
-    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _I64, _P]),
-    "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _P, _I64,
-                                      _P]),
+    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _SHARD, _P, _I64, _P]),
+    "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,
+                                      _P, _I64, _P]),
     "gs_tile_count": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P]),
     "gs_cumsum_scratch_bytes": (_I64, [_I64]),
     "gs_full_cumsum_i32": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _P]),
@@ -56,9 +70,11 @@ SIGNATURES = {
     "gs_sort_scratch_bytes": (_I64, [_I64, _I32]),
     "gs_radix_sort_pairs": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I32, _I32, _P, _I64, _P]),
     "gs_find_ranges": (ctypes.c_int, [_I64, _P, _I32, _I64, _P, _P]),
-    "gs_raster_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _P]),
+    "gs_raster_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _SHARD,
+                                      _P]),
     "gs_grad_row_floats": (_I32, [_I32]),
-    "gs_raster_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _P]),
+    "gs_raster_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _I32, _I32, _CFG, _P, _P, _P, _P, _P, _SHARD,
+                                      _P]),
     "gs_raster_bwd_unpack": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _P]),
     "gs_segmented_sort_pairs": (ctypes.c_int, [_I64, _I32, _P, _P, _P, _P, _I64, _P, _P, _P, _I64, _P]),
     "gs_optim_visibility_weights": (ctypes.c_int, [_I64, _P, _P, _P, _P, c_float, c_float, c_float, _P, _P, _P]),
@@ -159,27 +175,71 @@ def check(rc: int, what: str) -> None:
         raise RuntimeError(f"{what} failed ({rc}): {msg}")
 
 
-_CONFIGS = {}  # RasterConfig (frozen, hashable) -> its C struct
+_CONFIGS = {}  # (RasterConfig (frozen, hashable), cut scale, tuning) -> its C struct
 
 
-def make_config(config) -> GsRasterConfig:
-    cached = _CONFIGS.get(config)
+def make_config(config, cut_scale: float = 1.0) -> GsRasterConfig:
+    """cut_scale divides RasterConfig.forward_cut: the bound on what the forward's early stop drops is
+    forward_cut * max|feature|, so callers blending large features (z^2 up to far^2) pass that magnitude."""
+    key = (config, float(cut_scale), TUNING["wave_sub_blocks"], TUNING["no_heavy_split"])
+    cached = _CONFIGS.get(key)
     if cached is None:
-        cached = _CONFIGS[config] = _build_config(config)
+        cached = _CONFIGS[key] = _build_config(config, cut_scale)
     return cached
 
 
-def _build_config(config) -> GsRasterConfig:
+def make_shard(shard):
+    """None, or a parallel.RowShard -> byref(GsRowShard) for the C-ABI."""
+    if shard is None:
+        return None
+    return ctypes.byref(GsRowShard(int(shard.row_begin), int(shard.row_end), int(shard.band), int(shard.period),
+                                   int(shard.phase)))
+
+
+def _build_config(config, cut_scale: float = 1.0) -> GsRasterConfig:
     return GsRasterConfig(
         int(config.tile_size), int(config.pixel_stride[0]), int(config.pixel_stride[1]), int(config.antialias),
         int(config.use_alpha_blending), int(config.compute_point_heuristic),
         int(config.compute_visibility or config.compute_point_heuristic), float(config.clamp_margin),
         float(config.blur_cov), float(config.clamp_max_alpha), float(config.alpha_threshold),
-        float(config.saturate_threshold))
+        float(config.saturate_threshold), float(getattr(config, "forward_cut", 0.0)) / max(float(cut_scale), 1.0),
+        int(TUNING["wave_sub_blocks"]), int(TUNING["no_heavy_split"]))
+
+
+def on_tensor_device(fn):
+    """Run `fn` with the CUDA(HIP) current device set to the device of its first GPU tensor argument.  Every kernel
+    of the library launches on the CURRENT device's stream, and torch allocates scratch where the inputs live: with
+    tensors on cuda:1 while cuda:0 is current, device-1 pointers would go to a launch on device 0.  Wrapped around
+    every autograd forward / backward and every plain operator of the package."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index == torch.cuda.current_device():
+                    return fn(*args, **kwargs)
+                with torch.cuda.device(a.device):
+                    return fn(*args, **kwargs)
+        return fn(*args, **kwargs)
+    return wrapper
+
+
+def check_same_device(tensors) -> None:
+    """raises if GPU tensors of one call live on different devices (pure logic: testable without a GPU)"""
+    seen = None
+    for t in tensors:
+        if t is None or not getattr(t, "is_cuda", False):
+            continue
+        if seen is None:
+            seen = t.device
+        elif t.device != seen:
+            raise RuntimeError(f"tensors of one call on different devices: {seen} and {t.device}")
 
 
 def require_device(*tensors: torch.Tensor, dtype=torch.float32, what="tensor") -> None:
     """The operators run on MI355X only.  Anything else is an error, not a fallback."""
+    check_same_device(tensors)
     for t in tensors:
         if t is None:
             continue

@@ -39,11 +39,63 @@ static inline int gs_check_cfg(const GsRasterConfig* cfg) {
   return GS_OK;
 }
 
+// ---- screen-tile sharding (GsRowShard, include/gsplat_hip.h): owned tile rows <-> local rows.  Plain struct
+// arithmetic, usable on host and device.  `rows` = tile rows of the full image.
+struct GsShard {
+  int begin, end, band, period, phase;  // period == 1: every row of [begin, end) is owned
+  int local_rows;                       // number of owned rows
+};
+
+#ifdef __HIPCC__
+#define GS_HD __host__ __device__ __forceinline__
+#else
+#define GS_HD inline
+#endif
+
+GS_HD bool gs_shard_owns(const GsShard& s, int ty) {
+  if (ty < s.begin || ty >= s.end) return false;
+  return s.period == 1 || (ty / s.band) % s.period == s.phase;
+}
+GS_HD int gs_shard_local_row(const GsShard& s, int ty) {  // ty must be owned
+  return s.period == 1 ? ty - s.begin : (ty / (s.band * s.period)) * s.band + ty % s.band;
+}
+GS_HD int gs_shard_global_row(const GsShard& s, int local) {
+  return s.period == 1 ? local + s.begin : (local / s.band) * s.band * s.period + s.phase * s.band + local % s.band;
+}
+
+// validates `shard` against the image (NULL = whole image) and fills `out`
+static inline int gs_make_shard(const GsRowShard* shard, int rows, GsShard* out) {
+  if (shard == nullptr) {
+    out->begin = 0; out->end = rows; out->band = rows > 0 ? rows : 1; out->period = 1; out->phase = 0;
+    out->local_rows = rows;
+    return GS_OK;
+  }
+  GS_REQUIRE(shard->row_begin >= 0 && shard->row_begin <= shard->row_end && shard->row_end <= rows,
+             GS_ERR_INVALID_ARGUMENT, "shard rows [%d, %d) outside the image's %d tile rows", shard->row_begin,
+             shard->row_end, rows);
+  out->begin = shard->row_begin; out->end = shard->row_end;
+  if (shard->period <= 1) {
+    out->band = rows > 0 ? rows : 1; out->period = 1; out->phase = 0;
+    out->local_rows = out->end - out->begin;
+    return GS_OK;
+  }
+  GS_REQUIRE(shard->band >= 1 && shard->phase >= 0 && shard->phase < shard->period, GS_ERR_INVALID_ARGUMENT,
+             "shard band %d period %d phase %d", shard->band, shard->period, shard->phase);
+  GS_REQUIRE(shard->row_begin == 0 && shard->row_end == rows, GS_ERR_INVALID_ARGUMENT,
+             "an interleaved shard covers all tile rows (got [%d, %d) of %d)", shard->row_begin, shard->row_end, rows);
+  out->band = shard->band; out->period = shard->period; out->phase = shard->phase;
+  const int cycle = shard->band * shard->period, full = rows / cycle, rem = rows % cycle;
+  int tail = rem - shard->phase * shard->band;
+  tail = tail < 0 ? 0 : (tail > shard->band ? shard->band : tail);
+  out->local_rows = full * shard->band + tail;
+  return GS_OK;
+}
+
 // How many 8x8 pixel sub-blocks one rasterizer wave owns: 4 (a 16x16 region, 4 pixels per lane) when the
 // tile grid alone fills the chip (256 CUs x 4 SIMDs x ~8 waves); 2 or 1 for small grids (training-size
 // images, a tile-row strip of a sharded frame), which then run 2x / 4x as many waves at some extra
-// staging work per splat.  GS_RASTER_NB=1|2|4 overrides (tuning aid).  Results do not depend on it.
-int gs_raster_sub_blocks(int tile_size, int64_t num_tiles, int backward);
+// staging work per splat.  Results do not depend on it.
+int gs_raster_sub_blocks(const GsRasterConfig* cfg, int64_t num_tiles, int backward);
 
 // ------------------------------------------------------------------ device helpers
 #ifdef __HIPCC__

@@ -103,7 +103,23 @@ struct MapArgs {
   int Wp, Hp, tile_size, tiles_wide;
   float thr;
   int depth16;
+  GsShard sh;           // owned tile rows (the whole image when the call is not sharded)
 };
+
+// does [lo, hi) hold a tile row of the shard?
+__device__ __forceinline__ bool any_owned_row(const GsShard& sh, int lo, int hi) {
+  lo = max(lo, sh.begin);
+  hi = min(hi, sh.end);
+  if (lo >= hi) return false;
+  if (sh.period == 1 || hi - lo >= sh.band * sh.period) return true;
+  for (int ty = lo; ty < hi; ++ty)
+    if ((ty / sh.band) % sh.period == sh.phase) return true;
+  return false;
+}
+// local tile id of an owned tile
+__device__ __forceinline__ int local_tile(const MapArgs& a, int gx, int gy) {
+  return gs_shard_local_row(a.sh, gy) * a.tiles_wide + gx;
+}
 
 __device__ __forceinline__ int64_t live_count(const MapArgs& a) {
   if (a.v_dev == nullptr) return a.v;
@@ -262,13 +278,14 @@ struct RegionGrid {
   int tiles_x, tiles_y, regions_x, num_regions;
   int rg;    // region edge in tiles
   int win;   // window edge = rg + 2 RB; the LDS window holds win * win ints
+  int row0;  // first tile row the grid covers (a contiguous shard's first row; 0 otherwise)
 };
 
 __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs& a, const RegionGrid& rg) {
   const float ts = float(a.tile_size);
   int tx = int(floorf(g[0] / ts)), ty = int(floorf(g[1] / ts));
   tx = min(max(tx, 0), rg.tiles_x - 1);
-  ty = min(max(ty, 0), rg.tiles_y - 1);
+  ty = min(max(ty - rg.row0, 0), rg.tiles_y - 1);  // the region grid starts at the shard's first row
   return (ty / rg.rg) * rg.regions_x + (tx / rg.rg);
 }
 
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
     // strip when the frame is sharded) are left out of the ordering, so the counting and bucketing passes never
     // see them.  (A non-empty span whose tiles all fail the OBB test is rare and simply contributes nothing.)
     const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
-    const bool any = q.span_x > 0 && q.span_y > 0;
+    const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
     const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
     if (r >= 0) atomicAdd(&s_hist[r], 1);
@@ -390,11 +407,13 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
   if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
   for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) s_win[e] = 0;
   __syncthreads();
-  const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
+  // the window is laid out in full-image tile coordinates; rows the shard does not own stay zero
+  const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB + rg.row0;
   auto add_tile = [&](int gx, int gy) {
+    if (!gs_shard_owns(a.sh, gy)) return;
     const int lx = gx - wx0, ly = gy - wy0;
     if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_win[ly * WIN + lx], 1);
-    else atomicAdd(tile_hist + gx + gy * a.tiles_wide, 1);
+    else atomicAdd(tile_hist + local_tile(a, gx, gy), 1);
   };
   int i = 0;
   bool wide = false;
@@ -403,9 +422,11 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
     const GridQuery q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
     wide = q.span_x * q.span_y > WIDE_SPAN;
     if (!wide)
-      for (int ty = 0; ty < q.span_y; ++ty)
+      for (int ty = 0; ty < q.span_y; ++ty) {
+        if (!gs_shard_owns(a.sh, ty + q.min_ty)) continue;
         for (int tx = 0; tx < q.span_x; ++tx)
           if (test_tile(q, tx, ty, a.tile_size)) add_tile(tx + q.min_tx, ty + q.min_ty);
+      }
   }
   // Splats with a wide candidate span (hundreds of tiles for a floater that covers the screen) are walked by
   // the whole wave, 64 tiles per step: one lane looping over them alone would hold its workgroup for
@@ -424,7 +445,7 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
     const int c = s_win[e];
     if (c > 0) {
       const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
-      atomicAdd(tile_hist + gx + gy * a.tiles_wide, c);
+      atomicAdd(tile_hist + local_tile(a, gx, gy), c);
     }
   }
 }
@@ -444,7 +465,7 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
   if (!locate_chunk(blockIdx.x, rg, region_start, chunk_start, region, first, count)) return;
   for (int e = threadIdx.x; e < WIN_TILES; e += CHUNK) s_cnt[e] = 0;
   __syncthreads();
-  const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB;
+  const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB + rg.row0;
   const bool active = int(threadIdx.x) < count;
   const int lane = int(threadIdx.x & 63);
   GridQuery q;
@@ -460,7 +481,7 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
       int bit = 0;
       for (int ty = 0; ty < q.span_y; ++ty)
         for (int tx = 0; tx < q.span_x; ++tx, ++bit)
-          if (test_tile(q, tx, ty, a.tile_size)) {
+          if (gs_shard_owns(a.sh, ty + q.min_ty) && test_tile(q, tx, ty, a.tile_size)) {
             accept |= 1ull << bit;
             const int lx = tx + q.min_tx - wx0, ly = ty + q.min_ty - wy0;
             if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
@@ -474,7 +495,7 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
     const int total = w.span_x * w.span_y;
     for (int k = lane; k < total; k += 64) {
       const int ty = k / w.span_x, tx = k - ty * w.span_x;
-      if (!test_tile(w, tx, ty, a.tile_size)) continue;
+      if (!gs_shard_owns(a.sh, ty + w.min_ty) || !test_tile(w, tx, ty, a.tile_size)) continue;
       const int lx = tx + w.min_tx - wx0, ly = ty + w.min_ty - wy0;
       if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
     }
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
       const int gx = wx0 + e % WIN, gy = wy0 + e / WIN;
       // a tile dropped by the capacity clamp has a hugely negative cursor: the returned value says so
       // (no separate load in front of the atomic: the reservations of a workgroup must pipeline)
-      const int base = atomicAdd(cursors + gx + gy * a.tiles_wide, c);
+      const int base = atomicAdd(cursors + local_tile(a, gx, gy), c);
       s_base[e] = base < 0 ? -1 : base;
     }
     s_cnt[e] = 0;
@@ -500,7 +521,7 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
       if (s_base[e] < 0) return;
       slot = s_base[e] + atomicAdd(&s_cnt[e], 1);
     } else {
-      slot = atomicAdd(cursors + gx + gy * a.tiles_wide, 1);
+      slot = atomicAdd(cursors + local_tile(a, gx, gy), 1);
       if (slot < 0) return;
     }
     pairs[slot] = pair;
@@ -519,7 +540,8 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
     const int total = w.span_x * w.span_y;
     for (int k = lane; k < total; k += 64) {
       const int ty = k / w.span_x, tx = k - ty * w.span_x;
-      if (test_tile(w, tx, ty, a.tile_size)) place(tx + w.min_tx, ty + w.min_ty, pair);
+      if (gs_shard_owns(a.sh, ty + w.min_ty) && test_tile(w, tx, ty, a.tile_size))
+        place(tx + w.min_tx, ty + w.min_ty, pair);
     }
   }
 }
@@ -902,7 +924,7 @@ __global__ __launch_bounds__(256) void scan_apply(int64_t n, const int* in, cons
 }
 
 int fill_args(MapArgs& a, int64_t v, const float* points, const float* depth, int width, int height,
-              const GsRasterConfig* cfg, int depth16) {
+              const GsRasterConfig* cfg, int depth16, const GsRowShard* shard = nullptr) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "mapper: image size %dx%d", width, height);
   GS_REQUIRE(v >= 0 && v < (int64_t(1) << 31), GS_ERR_INVALID_ARGUMENT, "mapper: %lld gaussians", (long long)v);
@@ -914,7 +936,7 @@ int fill_args(MapArgs& a, int64_t v, const float* points, const float* depth, in
   a.tiles_wide = a.Wp / ts;
   a.thr = cfg->alpha_threshold;
   a.depth16 = depth16;
-  return GS_OK;
+  return gs_make_shard(shard, a.Hp / ts, &a.sh);
 }
 
 }  // namespace
@@ -946,7 +968,8 @@ MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
 RegionGrid make_grid(const MapArgs& a) {
   RegionGrid rg;
   rg.tiles_x = a.tiles_wide;
-  rg.tiles_y = a.Hp / a.tile_size;
+  rg.row0 = a.sh.period == 1 ? a.sh.begin : 0;
+  rg.tiles_y = a.sh.period == 1 ? a.sh.end - a.sh.begin : a.Hp / a.tile_size;
   rg.rg = RG_MIN;
   while (gs_div_up(rg.tiles_x, rg.rg) * gs_div_up(rg.tiles_y, rg.rg) > MAX_REGIONS) rg.rg *= 2;
   rg.win = rg.rg + 2 * RB;
@@ -963,12 +986,13 @@ extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
 
 extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                               const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges,
-                              int32_t* counts_out, int32_t* tile_order, void* scratch, int64_t scratch_bytes,
-                              void* stream) {
+                              int32_t* counts_out, int32_t* tile_order, const GsRowShard* shard, void* scratch,
+                              int64_t scratch_bytes, void* stream) {
   MapArgs a;
-  if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0)) return rc;
+  if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0, shard)) return rc;
   a.v_dev = v_dev;
-  const int num_tiles = a.tiles_wide * (a.Hp / a.tile_size);
+  GS_REQUIRE(a.sh.local_rows > 0, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: the shard owns no tile row");
+  const int num_tiles = a.tiles_wide * a.sh.local_rows;
   GS_REQUIRE(tile_ranges && counts_out && scratch, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: NULL buffer");
   GS_REQUIRE(scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
              "gs_map_prepare: scratch %lld < %lld bytes", (long long)scratch_bytes,
@@ -1011,13 +1035,13 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
 extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_count, const float* points,
                              const float* depth, int32_t width, int32_t height, const GsRasterConfig* cfg,
                              int32_t use_depth16, const int32_t* tile_ranges, int32_t* overlap_to_point,
-                             uint64_t* sorted_keys, void* pair_scratch, void* scratch, int64_t scratch_bytes,
-                             void* stream) {
+                             uint64_t* sorted_keys, void* pair_scratch, const GsRowShard* shard, void* scratch,
+                             int64_t scratch_bytes, void* stream) {
   MapArgs a;
-  if (int rc = fill_args(a, v, points, depth, width, height, cfg, use_depth16)) return rc;
+  if (int rc = fill_args(a, v, points, depth, width, height, cfg, use_depth16, shard)) return rc;
   a.v_dev = v_dev;
   if (k == 0 || v == 0) return GS_OK;
-  const int num_tiles = a.tiles_wide * (a.Hp / a.tile_size);
+  const int num_tiles = a.tiles_wide * a.sh.local_rows;
   GS_REQUIRE(points && depth && tile_ranges && overlap_to_point && pair_scratch && scratch, GS_ERR_INVALID_ARGUMENT,
              "gs_map_finish: NULL buffer");
   GS_REQUIRE(scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,

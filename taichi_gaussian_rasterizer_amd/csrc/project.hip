@@ -159,8 +159,7 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_row
 __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* st_rows, const int* block_offsets,
                                                       const int* block_counts, int num_blocks, float inv_far, float ndc_denom, float* points,
                                                       float* depth, float* ndc, int64_t* indexes, int* slot_of,
-                                                      int* num_visible, float* depth_feat, int depth_feat_stride,
-                                                      float mean_y_offset) {
+                                                      int* num_visible, float* depth_feat, int depth_feat_stride) {
   __shared__ int s_cnt[4];
   __shared__ int s_before[4];
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -189,8 +188,7 @@ __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* s
     if (vis) {
       slot = base + __popcll(b & ((1ull << lane) - 1ull));
       float* p = points + int64_t(slot) * 7;
-      // mean_y_offset: origin of a tile-row strip (a multiple of the tile size, so the subtraction is exact)
-      p[0] = r0.x; p[1] = r0.y - mean_y_offset; p[2] = r0.z; p[3] = r0.w; p[4] = r1.x; p[5] = r1.y; p[6] = r1.z;
+      p[0] = r0.x; p[1] = r0.y; p[2] = r0.z; p[3] = r0.w; p[4] = r1.x; p[5] = r1.y; p[6] = r1.z;
       depth[slot] = r1.w;
       if (depth_feat) {  // renderer.py:191-193: raster features [z, z^2, ...]
         depth_feat[int64_t(slot) * depth_feat_stride] = r1.w;
@@ -417,7 +415,7 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
                               int32_t width, int32_t height, double near_plane, double far_plane,
                               const GsRasterConfig* cfg, float* points, float* depth, float* ndc_depth,
                               int64_t* indexes, int32_t* slot_of, int32_t* num_visible, float* depth_features,
-                              int32_t depth_features_stride, float mean_y_offset, float* camera_pos, void* scratch,
+                              int32_t depth_features_stride, float* camera_pos, void* scratch,
                               int64_t scratch_bytes, void* stream) {
   ProjArgs a;
   if (int rc = fill(a, n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
@@ -449,8 +447,7 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
   if (!self_offsets)
     if (int rc = gs_full_cumsum_i32(nb, counts, offsets, scan_scratch, gs_cumsum_scratch_bytes(nb), s)) return rc;
   hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, s, n, st_rows, self_offsets ? nullptr : offsets, counts, nb, a.inv_far, a.ndc_denom,
-                     points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride,
-                     mean_y_offset);
+                     points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride);
   GS_CHECK_LAUNCH("gs_project_fwd/compact");
   return GS_OK;
 }

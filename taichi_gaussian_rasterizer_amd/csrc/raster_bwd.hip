@@ -22,8 +22,6 @@
 //
 // Roofline: algorithmic HBM bytes 8T + K(4+28+4F) + 8PF + 4(7+F)K; VALU-bound.
 
-#include <stdlib.h>
-
 #include "gs_common.h"
 
 namespace {
@@ -48,7 +46,16 @@ struct BwdArgs {
   const int* tile_order;  // optional launch order of the items (heaviest first)
   float cmax, thr, sat;
   int aa, heur;
+  GsShard sh;  // owned tile rows: tile ids are local, H is the full image height, the images hold the owned rows
 };
+
+// pixel origin of a (local) tile in the full image, and the row of the image buffers it starts at
+__device__ __forceinline__ void tile_origin(const BwdArgs& a, int tile, int& x0, int& y0, int& yout0) {
+  const int lty = tile / a.tiles_wide;
+  x0 = (tile - lty * a.tiles_wide) * a.tile_size;
+  y0 = gs_shard_global_row(a.sh, lty) * a.tile_size;
+  yout0 = lty * a.tile_size;
+}
 
 __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, float& ds_dx, float& ds_dsig) {
   // taichi_lib/generic.py:360-369
@@ -79,7 +86,8 @@ struct BwdShape {
 };
 
 template <int NB, int FP, int MODE>
-__device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, float* smem, int* s_idx) {
+__device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, int yout0, float* smem,
+                                                int* s_idx) {
   const int lane = threadIdx.x;
   constexpr bool FULL = MODE == 2, HEUR = MODE == 1;
   constexpr int NS = MODE == 2 ? 9 : MODE == 1 ? 8 : 6;  // sums per splat besides the F feature gradients
@@ -112,7 +120,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 #pragma unroll
     for (int c = 0; c < FP; ++c) gpix[b][c] = 0.0f;
     if (inb) {
-      const int64_t pix = int64_t(Y) * a.W + X;
+      const int64_t pix = int64_t(Y - y0 + yout0) * a.W + X;
 #pragma unroll
       for (int c = 0; c < FP; ++c)
         if (c < a.F) {
@@ -366,8 +374,10 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
     const int heavy = (NB > 1 && a.heavy) ? min(*a.heavy, a.heavy_cap) : 0;
     if (NB > 1 && b < 4 * heavy) {
       tile = a.tile_order[b >> 2];
-      const int x0 = (tile % a.tiles_wide) * 16 + (b & 1) * 8, y0 = (tile / a.tiles_wide) * 16 + ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, smem, s_idx);
+      int x0, y0, yout0;
+      tile_origin(a, tile, x0, y0, yout0);
+      x0 += (b & 1) * 8; y0 += ((b >> 1) & 1) * 8; yout0 += ((b >> 1) & 1) * 8;
+      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -380,10 +390,11 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
     tile = item / per_tile;
     quad = item - tile * per_tile;
   }
-  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
-  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
+  int x0, y0, yout0;
+  tile_origin(a, tile, x0, y0, yout0);
+  x0 += (quad % a.sub_x) * RW; y0 += (quad / a.sub_x) * RH; yout0 += (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, smem, s_idx);
+  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx);
 }
 
 template <int NB, int MODE>
@@ -417,7 +428,7 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
                              const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
                              int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order,
                              const int32_t* heavy_tiles, const float* image, const float* grad_image,
-                             float* grad_rows, void* stream) {
+                             float* grad_rows, const GsRowShard* shard, void* stream) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_bwd: image size %dx%d", width, height);
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
@@ -436,8 +447,10 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.row_floats = gs_grad_row_floats(num_features);
   a.tiles_wide = int(gs_div_up(width, ts));
   a.tile_size = ts;
-  const int num_tiles = a.tiles_wide * int(gs_div_up(height, ts));
-  const int nb = gs_raster_sub_blocks(ts, num_tiles, 1);
+  if (int rc = gs_make_shard(shard, int(gs_div_up(height, ts)), &a.sh)) return rc;
+  const int num_tiles = a.tiles_wide * a.sh.local_rows;
+  if (num_tiles == 0) return GS_OK;
+  const int nb = gs_raster_sub_blocks(cfg, num_tiles, 1);
   a.sub_x = ts / (nb == 1 ? 8 : 16);
   a.sub_y = ts / (nb == 4 ? 16 : 8);
   a.num_items = num_tiles * a.sub_x * a.sub_y;
@@ -445,9 +458,7 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.num_tiles = num_tiles;
   a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
   a.heavy_cap = num_tiles / 4;
-  if (const char* e = getenv("GS_RASTER_HEAVY")) {  // tuning aid: 0 = never split
-    if (e[0] == '0') a.heavy = nullptr;
-  }
+  if (cfg->tune_no_heavy_split) a.heavy = nullptr;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);

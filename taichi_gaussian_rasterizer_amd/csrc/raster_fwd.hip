@@ -22,8 +22,6 @@
 // Roofline: algorithmic HBM bytes K*(4 + 28 + 4F) + 16T + 4P(F+1); the kernel is
 // VALU-bound (about 20 VALU + 1 v_exp_f32 per evaluated pixel-splat pair).
 
-#include <stdlib.h>
-
 #include "gs_common.h"
 
 namespace {
@@ -46,8 +44,18 @@ struct FwdArgs {
   int heavy_cap;
   const int* tile_order;  // optional launch order of the items (heaviest first)  // tiles * sub * sub
   float cmax, thr, sat_level;
+  float keep;  // a region is walked while some pixel's accumulated weight is below this (1 - forward_cut)
   int blend, vis, aa;
+  GsShard sh;  // owned tile rows: tile ids are local, H is the full image height, the image holds the owned rows
 };
+
+// pixel origin of a (local) tile in the full image, and the row of the output buffer it starts at
+__device__ __forceinline__ void tile_origin(const FwdArgs& a, int tile, int& x0, int& y0, int& yout0) {
+  const int lty = tile / a.tiles_wide;
+  x0 = (tile - lty * a.tiles_wide) * a.tile_size;
+  y0 = gs_shard_global_row(a.sh, lty) * a.tile_size;
+  yout0 = lty * a.tile_size;
+}
 
 __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
   const float z = x * inv_sigma;
@@ -59,7 +67,7 @@ __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
 // MODE 0: blend only (lean); 1: blend + per-splat visibility (training with pruning statistics);
 // 2: runtime switches for quantile mode / antialias (+ visibility).
 template <int NB, int FP, int MODE>
-__device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0,
+__device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0, int yout0,
                                                 float4 (*s_geo)[MODE == 2 ? 3 : 2], float (*s_feat)[FP], float* s_vis,
                                                 int* s_idx) {
   constexpr bool FULL = MODE == 2, VIS = MODE >= 1;
@@ -84,15 +92,16 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 
   for (int g0 = range.x; g0 < range.y; g0 += 64) {
     // The reference's forward never stops (forward.py:84-128).  Once every pixel of the region has less than
-    // 2^-20 of its transmittance left, everything still to come changes a pixel by < 1e-6 in total (features are
-    // clamped colours; 20x below the parity tolerance), so the rest of a crowded tile's list is skipped.
+    // cfg->forward_cut of its transmittance left, everything still to come changes a pixel by less than
+    // forward_cut * max|feature| in total, so the rest of a crowded tile's list is skipped (forward_cut = 0: only
+    // where the f32 transmittance is exactly zero, i.e. every further weight is 0.0f -- the reference literally).
     // The same holds per 8x8 sub-block: a saturated one is masked out for the rest of the list.
     int live = (1 << NB) - 1;
     if (!FULL || a.blend) {
       live = 0;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
-        if (__ballot(Wt[b] < 1.0f - 9.5367431640625e-07f) != 0ull) live |= 1 << b;
+        if (__ballot(Wt[b] < a.keep) != 0ull) live |= 1 << b;
       if (live == 0) break;
     }
     const int cnt = min(64, range.y - g0);
@@ -210,7 +219,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
   for (int b = 0; b < NB; ++b) {
     if (!inb[b]) continue;
     const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
-    const int64_t pix = int64_t(Y) * a.W + X;
+    const int64_t pix = int64_t(Y - y0 + yout0) * a.W + X;
     float* out = a.image + pix * a.F;
 #pragma unroll
     for (int c = 0; c < FP; ++c)
@@ -237,8 +246,10 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
     const int heavy = (NB > 1 && a.heavy) ? min(*a.heavy, a.heavy_cap) : 0;
     if (NB > 1 && b < 4 * heavy) {
       tile = a.tile_order[b >> 2];
-      const int x0 = (tile % a.tiles_wide) * 16 + (b & 1) * 8, y0 = (tile / a.tiles_wide) * 16 + ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, MODE>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
+      int x0, y0, yout0;
+      tile_origin(a, tile, x0, y0, yout0);
+      x0 += (b & 1) * 8; y0 += ((b >> 1) & 1) * 8; yout0 += ((b >> 1) & 1) * 8;
+      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, s_geo, s_feat, s_vis, s_idx);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -251,10 +262,11 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
     tile = item / per_tile;
     quad = item - tile * per_tile;
   }
-  const int x0 = (tile % a.tiles_wide) * a.tile_size + (quad % a.sub_x) * RW;
-  const int y0 = (tile / a.tiles_wide) * a.tile_size + (quad / a.sub_x) * RH;
+  int x0, y0, yout0;
+  tile_origin(a, tile, x0, y0, yout0);
+  x0 += (quad % a.sub_x) * RW; y0 += (quad / a.sub_x) * RH; yout0 += (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_fwd_body<NB, FP, MODE>(a, tile, x0, y0, s_geo, s_feat, s_vis, s_idx);
+  raster_fwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, s_geo, s_feat, s_vis, s_idx);
 }
 
 template <int NB, int MODE>
@@ -273,7 +285,8 @@ int launch_fp(const FwdArgs& a, hipStream_t s) {
 extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* points, const float* features,
                              const int32_t* tile_ranges, const int32_t* overlap_to_point, int64_t k, int32_t width,
                              int32_t height, const GsRasterConfig* cfg, const int32_t* tile_order,
-                             const int32_t* heavy_tiles, float* image, float* alpha, float* visibility, void* stream) {
+                             const int32_t* heavy_tiles, float* image, float* alpha, float* visibility,
+                             const GsRowShard* shard, void* stream) {
   if (int rc = gs_check_cfg(cfg)) return rc;
   GS_REQUIRE(width > 0 && height > 0, GS_ERR_INVALID_ARGUMENT, "gs_raster_fwd: image size %dx%d", width, height);
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES, GS_ERR_UNSUPPORTED,
@@ -290,8 +303,10 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   a.W = width; a.H = height; a.F = num_features;
   a.tiles_wide = int(gs_div_up(width, ts));
   a.tile_size = ts;
-  const int num_tiles = a.tiles_wide * int(gs_div_up(height, ts));
-  const int nb = gs_raster_sub_blocks(ts, num_tiles, 0);
+  if (int rc = gs_make_shard(shard, int(gs_div_up(height, ts)), &a.sh)) return rc;
+  const int num_tiles = a.tiles_wide * a.sh.local_rows;
+  if (num_tiles == 0) return GS_OK;
+  const int nb = gs_raster_sub_blocks(cfg, num_tiles, 0);
   a.sub_x = ts / (nb == 1 ? 8 : 16);
   a.sub_y = ts / (nb == 4 ? 16 : 8);
   a.num_items = num_tiles * a.sub_x * a.sub_y;
@@ -300,11 +315,11 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   // the split needs the 2x2-quadrant geometry of a 16-pixel tile and a launch order to index into
   a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
   a.heavy_cap = num_tiles / 4;
-  if (const char* e = getenv("GS_RASTER_HEAVY")) {  // tuning aid: 0 = never split
-    if (e[0] == '0') a.heavy = nullptr;
-  }
+  if (cfg->tune_no_heavy_split) a.heavy = nullptr;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
+  // Wt < keep  <=>  transmittance 1 - Wt above the cut (cut <= 0: walk while Wt < 1, i.e. while anything can change)
+  a.keep = cfg->forward_cut > 0.0f ? 1.0f - cfg->forward_cut : 1.0f;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int mode = (!a.blend || a.aa) ? 2 : a.vis ? 1 : 0;

@@ -42,13 +42,20 @@ class RasterConfig:
     compute_point_heuristic: bool = False  # implies compute_visibility
     compute_visibility: bool = False
 
+    # NOT a reference field (keyword-only, so reference call sites are unaffected).  The reference's forward blends
+    # down a tile's whole list (rasterizer/forward.py:84-128); this forward stops a 16x16 region once every pixel of
+    # it has less than forward_cut of its transmittance left, which changes a pixel by < forward_cut * max|feature|.
+    # 0.0 reproduces the reference literally.  With render_depth the cut is divided by far^2 (the z^2 feature).
+    forward_cut: float = 2.0 ** -20
+
     def __post_init__(self):
         if not isinstance(self.tile_size, int) or isinstance(self.tile_size, bool):
             raise TypeError(f"tile_size must be int, got {type(self.tile_size).__name__}")
         if not (isinstance(self.pixel_stride, tuple) and len(self.pixel_stride) == 2
                 and all(isinstance(x, int) for x in self.pixel_stride)):
             raise TypeError(f"pixel_stride must be Tuple[int, int], got {self.pixel_stride!r}")
-        for name in ("clamp_margin", "blur_cov", "clamp_max_alpha", "alpha_threshold", "saturate_threshold"):
+        for name in ("clamp_margin", "blur_cov", "clamp_max_alpha", "alpha_threshold", "saturate_threshold",
+                     "forward_cut"):
             if not isinstance(getattr(self, name), float):
                 raise TypeError(f"{name} must be float, got {type(getattr(self, name)).__name__}")
         for name in ("antialias", "use_alpha_blending", "compute_point_heuristic", "compute_visibility"):

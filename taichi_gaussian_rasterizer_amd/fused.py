@@ -43,24 +43,27 @@ def _off(t: torch.Tensor, floats: int) -> ctypes.c_void_p:
 
 class _FusedRender(torch.autograd.Function):
     @staticmethod
+    @nv.on_tensor_device
     def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                 image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                render_median: bool = False, strip=None, group=None):
+                render_median: bool = False, shard=None, group=None, holder=None):
         nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                           what="render_gaussians")
         lib = nv.lib()
         dev = position.device
         n = position.shape[0]
         w, full_h = int(image_size[0]), int(image_size[1])
-        # tile-row strip of a sharded frame (parallel.py): projection and culling see the full image, the
-        # mapper and the rasterizer see a (w, y1-y0) image whose splats are shifted up by y0
-        y0, y1 = (0, full_h) if strip is None else (int(strip[0]), int(strip[1]))
-        h = y1 - y0
+        # sharded frame (parallel.RowShard): everything stays in full-image coordinates; the mapper and the
+        # rasterizer skip the tile rows this rank does not own and the images hold the owned pixel rows only
+        h = full_h if shard is None else shard.local_height
+        sh = nv.make_shard(shard)
         C = feature.shape[1]
         degree = check_sh_degree(feature) if feature.dim() == 3 else -1  # -1: plain (N, C) features, no SH
         F = C + (2 if render_depth else 0)
         col0 = F - C
         cfg = nv.make_config(config)
+        # what the forward's early stop may drop is bounded by forward_cut * max|feature|: z^2 reaches far^2
+        rcfg = nv.make_config(config, cut_scale=float(depth_range[1]) ** 2) if render_depth else cfg
         ts = config.tile_size
         tile_shape = (-(-h // ts), -(-w // ts))
         num_tiles = tile_shape[0] * tile_shape[1]
@@ -85,7 +88,7 @@ class _FusedRender(torch.autograd.Function):
                                     nv.ptr(T), nv.ptr(proj), w, full_h, float(depth_range[0]), float(depth_range[1]),
                                     cfg, nv.ptr(points), nv.ptr(depth), nv.ptr(ndc), nv.ptr(indexes),
                                     nv.ptr(slot_of), nv.ptr(counts), nv.ptr(feats) if render_depth else None, F,
-                                    float(y0), nv.ptr(cam_pos), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
+                                    nv.ptr(cam_pos), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
         v_dev = nv.ptr(counts)
         if degree >= 0:
             nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
@@ -96,19 +99,29 @@ class _FusedRender(torch.autograd.Function):
 
         tile_ranges = torch.empty((*tile_shape, 2), dtype=torch.int32, device=dev)
         tile_order = torch.empty((num_tiles,), dtype=torch.int32, device=dev)  # heaviest tiles first
-        mbytes = lib.gs_map_scratch_bytes(n, num_tiles)
+        mbytes = lib.gs_map_scratch_bytes(n, max(num_tiles, 1))
         mscratch = torch.empty((mbytes,), dtype=torch.uint8, device=dev)
         want_vis = config.compute_visibility or config.compute_point_heuristic
-        key = (n, w, full_h, y0, y1, ts, bool(use_depth16))
+        key = (n, w, full_h, shard, ts, bool(use_depth16))
         hint = _K_HINT.get(key)
         k_cap = 0 if hint is None else int(hint[0] * 1.25) + 4096
         tile_hint = 0 if hint is None else -max(int(hint[1]), 1)  # sizing hint only; fuller tiles are still sorted
         host_counts = _pinned_counts(dev)
         ready = torch.cuda.Event()
 
+        def no_rows():
+            # this rank owns no tile row (more ranks than rows): nothing to map or rasterize, only V is needed
+            counts[4:8] = 0
+            host_counts.copy_(counts, non_blocking=True)
+            ready.record()
+            return (torch.empty((0,), dtype=torch.int32, device=dev), torch.empty((0, w, F), **f32),
+                    torch.empty((0, w), **f32), torch.zeros((n,), **f32) if want_vis else None)
+
         def map_and_raster(k_cap):
-            nv.check(lib.gs_map_prepare(n, v_dev, nv.ptr(points), w, h, cfg, k_cap, nv.ptr(tile_ranges),
-                                        _off(counts, 4), nv.ptr(tile_order), nv.ptr(mscratch), mbytes, s),
+            if num_tiles == 0:
+                return no_rows()
+            nv.check(lib.gs_map_prepare(n, v_dev, nv.ptr(points), w, full_h, cfg, k_cap, nv.ptr(tile_ranges),
+                                        _off(counts, 4), nv.ptr(tile_order), sh, nv.ptr(mscratch), mbytes, s),
                      "gs_map_prepare")
             # V, K and the overflow flag are final here: copy them out asynchronously and keep enqueueing;
             # the host waits on this event while the sort and the rasterizer are still running
@@ -119,16 +132,16 @@ class _FusedRender(torch.autograd.Function):
                 k_cap = max(int(host_counts[4]), 1)
             o2p = torch.empty((k_cap,), dtype=torch.int32, device=dev)
             pairs = torch.empty((k_cap,), dtype=torch.int64, device=dev)
-            nv.check(lib.gs_map_finish(n, v_dev, k_cap, tile_hint, nv.ptr(points), nv.ptr(ndc), w, h, cfg,
+            nv.check(lib.gs_map_finish(n, v_dev, k_cap, tile_hint, nv.ptr(points), nv.ptr(ndc), w, full_h, cfg,
                                        int(use_depth16),
-                                       nv.ptr(tile_ranges), nv.ptr(o2p), None, nv.ptr(pairs), nv.ptr(mscratch),
+                                       nv.ptr(tile_ranges), nv.ptr(o2p), None, nv.ptr(pairs), sh, nv.ptr(mscratch),
                                        mbytes, s), "gs_map_finish")
             image = torch.empty((h, w, F), **f32)
             alpha = torch.empty((h, w), **f32)
             vis = torch.zeros((n,), **f32) if want_vis else None
             nv.check(lib.gs_raster_fwd(n, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), k_cap,
-                                       w, h, cfg, nv.ptr(tile_order), _off(counts, 7), nv.ptr(image), nv.ptr(alpha),
-                                       nv.ptr(vis), s),
+                                       w, full_h, rcfg, nv.ptr(tile_order), _off(counts, 7), nv.ptr(image),
+                                       nv.ptr(alpha), nv.ptr(vis), sh, s),
                      "gs_raster_fwd")
             return o2p, image, alpha, vis
 
@@ -155,14 +168,16 @@ class _FusedRender(torch.autograd.Function):
         # render_median_depth: a second, non-blended forward over the same tile lists that keeps the depth of the splat
         # taking each pixel past half opacity (reference renderer.py:203-208); no gradient
         median = torch.empty((0,), **f32)
-        if render_median:
+        if render_median and num_tiles == 0:
+            median = torch.empty((0, w), **f32)
+        if render_median and num_tiles > 0:
             from dataclasses import replace as _replace
             pick = nv.make_config(_replace(config, use_alpha_blending=False, saturate_threshold=0.5,
                                            compute_visibility=False, compute_point_heuristic=False))
             median, covered = torch.empty((h, w), **f32), torch.empty((h, w), **f32)
             nv.check(lib.gs_raster_fwd(n, 1, nv.ptr(points), nv.ptr(depth), nv.ptr(tile_ranges), nv.ptr(o2p),
-                                       o2p.shape[0], w, h, pick, nv.ptr(tile_order), _off(counts, 7), nv.ptr(median),
-                                       nv.ptr(covered), None, s), "gs_raster_fwd")
+                                       o2p.shape[0], w, full_h, pick, nv.ptr(tile_order), _off(counts, 7),
+                                       nv.ptr(median), nv.ptr(covered), None, sh, s), "gs_raster_fwd")
 
         points_v, depth_v, indexes_v = points[:V], depth[:V], indexes[:V]
         empty = torch.empty((0,), **f32)
@@ -170,8 +185,9 @@ class _FusedRender(torch.autograd.Function):
         heur = torch.zeros((V, 2), **f32) if config.compute_point_heuristic else torch.empty((0, 2), **f32)
 
         ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, full_h=full_h, F=F, C=C, col0=col0, degree=degree, config=config,
-                        render_depth=render_depth, group=group, sharded=strip is not None)
+                        render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]))
         ctx.heur = heur
+        ctx.holder = holder
         # outputs nobody differentiates through (projected splats, depths) must not cost zero-filled gradients
         ctx.set_materialize_grads(False)
         ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of,
@@ -182,6 +198,7 @@ class _FusedRender(torch.autograd.Function):
         return out_image, alpha, points_v, depth_v, indexes_v, vis_out, heur, img_depth, img_var, median
 
     @staticmethod
+    @nv.on_tensor_device
     def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var,
                  _g_median=None):
         (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
@@ -192,10 +209,11 @@ class _FusedRender(torch.autograd.Function):
         n, V, K, w, h, F, C, col0 = m["n"], m["V"], m["K"], m["w"], m["h"], m["F"], m["C"], m["col0"]
         config = m["config"]
         cfg = nv.make_config(config)
+        sh = nv.make_shard(m["shard"])
         s = nv.stream()
         RS = lib.gs_grad_row_floats(F)
         rows = torch.zeros((max(V, 1), RS), dtype=torch.float32, device=dev)
-        if m["render_depth"] and V > 0 and any(g is not None for g in (g_image, g_img_depth, g_img_var)):
+        if m["render_depth"] and V > 0 and h > 0 and any(g is not None for g in (g_image, g_img_depth, g_img_var)):
             # assemble the gradient of the rasterized (H,W,2+C) image from the three upstream gradients
             gf_ = g_image.contiguous() if g_image is not None else None
             gd_ = g_img_depth.contiguous() if g_img_depth is not None else None
@@ -204,41 +222,43 @@ class _FusedRender(torch.autograd.Function):
             g_image = torch.empty((h, w, F), dtype=torch.float32, device=dev)
             nv.check(lib.gs_depth_split_bwd(h * w, C, nv.ptr(img_depth), nv.ptr(alpha), 1e-6, nv.ptr(gf_), nv.ptr(gd_),
                                             nv.ptr(gv_), nv.ptr(g_image), s), "gs_depth_split_bwd")
-        if g_image is not None and V > 0:
+        if g_image is not None and V > 0 and h > 0 and K > 0:
             gi = g_image.contiguous()
             nv.require_device(gi, what="render_gaussians backward")
-            nv.check(lib.gs_raster_bwd(V, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), K, w, h,
-                                       cfg, nv.ptr(tile_order), _off(counts, 7), nv.ptr(image), nv.ptr(gi),
-                                       nv.ptr(rows), s),
+            nv.check(lib.gs_raster_bwd(V, F, nv.ptr(points), nv.ptr(feats), nv.ptr(tile_ranges), nv.ptr(o2p), K, w,
+                                       m["full_h"], cfg, nv.ptr(tile_order), _off(counts, 7), nv.ptr(image),
+                                       nv.ptr(gi), nv.ptr(rows), sh, s),
                      "gs_raster_bwd")
         if config.compute_point_heuristic and V > 0:
             ctx.heur.copy_(rows[:V, 7 + F:9 + F])
-        # gradients a caller attached to the projected splats / depths themselves (e.g. a regulariser)
-        if g_points is not None and V > 0:
-            rows[:V, :7] += g_points
+
+        def add_attached(pts_rows):
+            # gradients a caller attached to the projected splats / depths themselves (e.g. a regulariser): every
+            # rank of a sharded frame holds the same, complete one, so it is added AFTER the partial sums are reduced
+            if g_points is not None and V > 0:
+                pts_rows[:V, :7] += g_points
+            if g_depth is not None and V > 0 and m["render_depth"]:
+                pts_rows[:V, 7] += g_depth.reshape(-1)
+
         extra_depth = None
-        if g_depth is not None and V > 0:
-            if m["render_depth"]:
-                rows[:V, 7] += g_depth.reshape(-1)
-            else:
-                extra_depth = g_depth.contiguous()
+        if g_depth is not None and V > 0 and not m["render_depth"]:
+            extra_depth = g_depth.contiguous()
 
         g_feat, g_feat_stride = _off(rows, 7 + col0), RS     # dL/d(SH colour) columns
         g_pts, g_pts_stride = rows, RS                        # dL/d(points) [+ depth feature] columns
         wait_points = None
-        if m["sharded"]:
-            # Every rank rendered a different strip: the per-Gaussian partial gradients are summed over the
+        if m["shard"] is not None:
+            # Every rank rendered different rows: the per-Gaussian partial gradients are summed over the
             # ranks, 4*(7+F) bytes per visible Gaussian in all.  Two collectives, colour columns first: the SH
             # adjoint only needs those and runs while the splat columns are still in flight.
-            import torch.distributed as dist
+            from .parallel import _reduce_partial_gradients
             pf = rows[:, 7 + col0:7 + F].contiguous()
             pp = rows[:, :7 + col0].contiguous()
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size(m["group"]) > 1:
-                wf = dist.all_reduce(pf, op=dist.ReduceOp.SUM, group=m["group"], async_op=True)
-                wait_points = dist.all_reduce(pp, op=dist.ReduceOp.SUM, group=m["group"], async_op=True)
-                wf.wait()
+            wait_points = _reduce_partial_gradients(pf, pp, m["group"])
             g_feat, g_feat_stride = nv.ptr(pf), C
             g_pts, g_pts_stride = pp, 7 + col0
+        else:
+            add_attached(rows)
 
         d_feature = torch.empty_like(feature)
         # camera matrix under optimisation: the SH view direction depends on the camera centre = inverse(T)[:3, 3]
@@ -256,6 +276,16 @@ class _FusedRender(torch.autograd.Function):
                      "gs_feature_gather_bwd")
         if wait_points is not None:
             wait_points.wait()
+        if m["shard"] is not None:
+            add_attached(g_pts)
+        # `Rendering.gaussians2d` is an OUTPUT of this node, so autograd alone would leave its .grad without the
+        # rasterizer's dL/d(splat) (which never leaves the node).  The reference feeds that very tensor to rasterize,
+        # so `gaussians2d.retain_grad()` + `viewspace_gradient` (renderer.py:234-239) is the classic densification
+        # signal there: publish the complete gradient (summed over the ranks of a sharded frame) on it.
+        out = ctx.holder.get("gaussians2d") if ctx.holder else None
+        out = out() if out is not None else None
+        if out is not None and out.retains_grad and V > 0:
+            out.grad = g_pts[:V, :7].clone()
 
         need_T, need_proj = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
         d_pos, d_ls = torch.empty_like(position), torch.empty_like(log_scaling)
@@ -279,7 +309,8 @@ class _FusedRender(torch.autograd.Function):
                 dY = torch.zeros((4, 4), dtype=torch.float64)
                 dY[:3, 3] = d_centre.cpu().double()
                 d_T = d_T + (-(Y.T @ dY @ Y.T)).to(device=dev, dtype=torch.float32)
-        return d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None, None
+        return (d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None, None,
+                None)
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
@@ -295,15 +326,20 @@ def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth:
 
 
 def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                 strip=None, group=None, render_median_depth: bool = False):
-    """strip=(y0, y1): render only those rows (a multiple-of-tile_size origin); `gaussians2d` of the result
-    then holds strip-local means (mean.y - y0).  See parallel.render_gaussians_sharded."""
+                 shard=None, group=None, render_median_depth: bool = False):
+    """shard (parallel.RowShard): render only the tile rows this rank owns; the images then hold those pixel rows,
+    everything per-Gaussian (`gaussians2d` included) stays in full-image coordinates.
+    See parallel.render_gaussians_sharded."""
+    import weakref
+
     from .renderer import Rendering
+    holder = {}
     image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var, median = _FusedRender.apply(
         gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
         gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
         camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
-        use_depth16, render_median_depth, strip, group)
+        use_depth16, render_median_depth, shard, group, holder)
+    holder["gaussians2d"] = weakref.ref(g2d)
     indexes._gs_unique = True
     if not render_depth:
         img_depth = img_var = None

@@ -14,6 +14,7 @@ from .. import _native as nv
 _KEY_BYTES = {torch.int32: 4, torch.uint32: 4, torch.int64: 8, torch.uint64: 8}
 
 
+@nv.on_tensor_device
 def full_cumsum(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     """Exclusive scan with the total appended: out has x.shape[0]+1 entries; returns (out, total)."""
     assert x.is_cuda, f"full_cumsum: device must be a cuda device, got {x.device}"
@@ -32,6 +33,7 @@ def full_cumsum(x: torch.Tensor) -> Tuple[torch.Tensor, int]:
     return out, int(out[n].item())
 
 
+@nv.on_tensor_device
 def radix_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_bit=0, end_bit=None):
     """Stable ascending sort of (key, value) pairs on key bits [start_bit, end_bit); returns new tensors.
     Keys are compared as UNSIGNED integers of their width (the mapper's keys are non-negative)."""
@@ -58,6 +60,7 @@ def radix_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_bit=0, end_
     return keys_out, values_out
 
 
+@nv.on_tensor_device
 def segmented_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_offset: torch.Tensor,
                          end_offset: torch.Tensor):
     """Ascending sort of (key, value) pairs inside each segment [start_offset[s], end_offset[s]); returns new
@@ -87,6 +90,7 @@ def segmented_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_offset:
     return keys_out, values_out
 
 
+@nv.on_tensor_device
 def radix_argsort(keys: torch.Tensor):
     idx = torch.arange(keys.shape[0], dtype=torch.int32, device=keys.device)
     _, idx = radix_sort_pairs(keys, idx)

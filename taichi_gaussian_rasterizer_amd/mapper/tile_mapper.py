@@ -42,6 +42,7 @@ def _validate(gaussians, depth, image_size, config, use_depth16):
 
 
 @torch.no_grad()
+@nv.on_tensor_device
 def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple[Integral, Integral],
                  config: RasterConfig, use_depth16: bool = False, return_keys: bool = False):
     """maps gaussians to tiles, sorted by depth (front to back).
@@ -68,7 +69,7 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
     nbytes = lib.gs_map_scratch_bytes(v, num_tiles)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     nv.check(lib.gs_map_prepare(v, None, nv.ptr(g), w, h, cfg, 0, nv.ptr(tile_ranges), nv.ptr(counts), None,
-                                nv.ptr(scratch), nbytes, nv.stream()), "gs_map_prepare")
+                                None, nv.ptr(scratch), nbytes, nv.stream()), "gs_map_prepare")
     k, max_tile = (int(x) for x in counts[:2].tolist())  # host sync (reference: full_cumsum.cu:45)
     overlap_to_point = torch.empty((k,), dtype=torch.int32, device=dev)
     keys = torch.empty((k,), dtype=torch.int64, device=dev) if return_keys else None
@@ -76,13 +77,14 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
         pairs = torch.empty((k,), dtype=torch.int64, device=dev)
         nv.check(lib.gs_map_finish(v, None, k, max_tile, nv.ptr(g), nv.ptr(d), w, h, cfg, int(use_depth16),
                                    nv.ptr(tile_ranges), nv.ptr(overlap_to_point), nv.ptr(keys), nv.ptr(pairs),
-                                   nv.ptr(scratch), nbytes, nv.stream()), "gs_map_finish")
+                                   None, nv.ptr(scratch), nbytes, nv.stream()), "gs_map_finish")
     if return_keys:
         return overlap_to_point, tile_ranges, keys
     return overlap_to_point, tile_ranges
 
 
 @torch.no_grad()
+@nv.on_tensor_device
 def map_to_tiles_reference_stages(gaussians: torch.Tensor, depth: torch.Tensor,
                                   image_size: Tuple[Integral, Integral], config: RasterConfig,
                                   use_depth16: bool = False, return_keys: bool = False):

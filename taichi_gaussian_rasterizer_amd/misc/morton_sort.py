@@ -12,6 +12,7 @@ from .. import _native as nv
 from ..hip_lib import radix_sort_pairs
 
 
+@nv.on_tensor_device
 def morton_codes(points: torch.Tensor, resolution: float, size: int = 2 ** 20) -> torch.Tensor:
     """(N) int64 tensor holding the unsigned 63-bit codes of the reference's Grid.morton_code64 for the
     grid `grid_at_resolution(points, resolution, size)` (lower = per-axis minimum, cell edge = resolution)."""

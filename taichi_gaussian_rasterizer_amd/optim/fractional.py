@@ -49,12 +49,13 @@ class _Rows:
         return self.kind != "scalar"
 
     def moments(self):
-        """(first moment (N, D), second moment (N, D) or (N)), created on first use"""
+        """(first moment (N, D), second moment (N, D) or (N)), created on first use.  Keys as in the reference's
+        checkpoints (optim/util.py:5-18): first moment under 'v', second moment under 'm'."""
         st = self.state
-        if "m" not in st:
-            st["m"] = torch.zeros_like(self.param)
-            st["v"] = self.param.new_zeros(self.num_points) if self.per_row_moment else torch.zeros_like(self.param)
-        return st["m"], st["v"]
+        if "v" not in st:
+            st["v"] = torch.zeros_like(self.param)
+            st["m"] = self.param.new_zeros(self.num_points) if self.per_row_moment else torch.zeros_like(self.param)
+        return st["v"], st["m"]
 
     def shared(self, key: str) -> torch.Tensor:
         """an (N) float32 counter kept in this group's state (the first group carries the optimizer-wide ones)"""
@@ -69,6 +70,14 @@ def _launch(rows: _Rows, algorithm: int, indexes, weight, total_weight, grad, ro
     opt = rows.options
     grad, indexes, weight = grad.contiguous(), indexes.contiguous(), weight.contiguous()
     scale = None if row_scale is None else row_scale.contiguous()
+    # a state dict from elsewhere may hold anything under these keys: the kernel indexes m[idx * D + j] and
+    # v[idx] / v[idx * D + j] without further checks
+    second = (rows.num_points,) if rows.per_row_moment else tuple(rows.param.shape)
+    assert tuple(m.shape) == tuple(rows.param.shape), \
+        f"{rows.name}: first moment (state['v']) has shape {tuple(m.shape)}, expected {tuple(rows.param.shape)}"
+    assert tuple(v.shape) == second, \
+        f"{rows.name}: second moment (state['m']) has shape {tuple(v.shape)}, expected {second}"
+    m, v = m.contiguous(), v.contiguous()
     nv.require_device(grad, weight, m, v, total_weight, scale, what="optimizer step")
     nv.require_device(indexes, dtype=torch.int64, what="optimizer step indexes")
     count, width = indexes.shape[0], rows.param.shape[1]

@@ -1,7 +1,8 @@
-"""Per-group optimizer state accessors (reference optim/util.py:5-38).  Note the reference's return order: the FIRST
-value is what its kernels receive as the first moment (N, D), the second the second moment -- (N) for vector groups --
-although it keeps them under the keys 'v' and 'm'.  This package stores first/second moment as 'm'/'v'
-(fractional.py `_Rows.moments`); these helpers return the same pair in the same order."""
+"""Per-group optimizer state accessors (reference optim/util.py:5-38).  CHECKPOINT FORMAT, kept exactly: the
+reference stores the FIRST moment (N, D) under the key 'v' and the SECOND moment -- (N) for vector groups, (N, D) for
+scalar ones -- under the key 'm' (its `m, v = get_vector_state(...)` unpacks ('v', 'm') in that order,
+optim/fractional.py:117-120).  A state dict written by the reference therefore loads into this package unchanged
+(`ParameterClass.load_state_dict`), and vice versa."""
 from __future__ import annotations
 
 import torch
@@ -12,17 +13,19 @@ def _rows(param: torch.Tensor) -> torch.Tensor:
 
 
 def get_vector_state(state: dict, param: torch.Tensor):
-    if "m" not in state:
-        state["m"] = torch.zeros_like(_rows(param))
-        state["v"] = torch.zeros(param.shape[0], dtype=param.dtype, device=param.device)
-    return state["m"], state["v"]
+    """(first moment (N, D), second moment (N))"""
+    if "v" not in state:
+        state["v"] = torch.zeros_like(_rows(param))
+        state["m"] = torch.zeros(param.shape[0], dtype=param.dtype, device=param.device)
+    return state["v"], state["m"]
 
 
 def get_scalar_state(state: dict, param: torch.Tensor):
-    if "m" not in state:
-        state["m"] = torch.zeros_like(_rows(param))
+    """(first moment (N, D), second moment (N, D))"""
+    if "v" not in state:
         state["v"] = torch.zeros_like(_rows(param))
-    return state["m"], state["v"]
+        state["m"] = torch.zeros_like(_rows(param))
+    return state["v"], state["m"]
 
 
 def _float_counter(state: dict, key: str, shape, device) -> torch.Tensor:

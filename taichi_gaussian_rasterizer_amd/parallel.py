@@ -1,4 +1,4 @@
-"""Multi-GPU rendering: screen tiles shard across ranks, one RCCL all-reduce of per-Gaussian
+"""Multi-GPU rendering: screen tiles shard across ranks, one RCCL exchange of per-Gaussian
 gradients (the reference has no distributed code at all).
 
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  Every rank holds the
@@ -6,23 +6,31 @@ full, replicated Gaussian set and for each frame:
 
   1. projects all N Gaussians and evaluates SH colour (replicated: 236 B/Gaussian read, cheaper than
      exchanging projected splats, and it keeps the visible set identical everywhere);
-  2. owns a contiguous strip of tile rows.  The strip is rendered as an ordinary (W, strip_h) image
-     after shifting the projected means by the strip origin (an exact f32 subtraction: the origin is a
-     multiple of the tile size), so the unmodified mapper / rasterizer kernels are reused;
-  3. evaluates the loss on its strip; the rasterizer backward yields PARTIAL gradients for the
+  2. owns a set of tile ROWS of the image (`RowShard`): one contiguous strip, or -- `interleave=b` -- bands of b
+     tile rows dealt round-robin over the ranks (load balance on real scenes, where the splats crowd a part of
+     the screen).  The mapper and the rasterizer work in full-image coordinates and simply skip the rows they do
+     not own (GsRowShard in include/gsplat_hip.h), so a shard's tiles get exactly the lists and pixels of the
+     unsharded frame and `Rendering.gaussians2d` is the same tensor on every rank;
+  3. evaluates the loss on its rows; the rasterizer backward yields PARTIAL gradients for the
      projected splats (V,7), their features (V,C) and depths (V,1);
-  4. all-reduces those partial gradients -- ONE collective of 4*(7+C+1)*V bytes
-     (40 B/Gaussian, vs 236 B/Gaussian if the final parameter gradients were reduced instead);
+  4. all-reduces those partial gradients -- 4*(7+C+1)*V bytes (40 B/Gaussian, vs 236 B/Gaussian if the final
+     parameter gradients were reduced instead), as two collectives, colour columns first, so that the SH adjoint
+     runs while the splat columns are in flight.  EVERY rank issues the same two collectives with the same shapes,
+     also one that owns no row;
   5. runs SH / projection backward redundantly, so every rank ends with identical, complete
      parameter gradients (drop-in for a replicated optimizer).
 
 The stage operators are injectable (`ops`) so the sharding + collective logic is exercised on CPU
-with the gloo backend in tests/ (stage callables backed by the CPU oracle there).
+with the gloo backend in tests/ (stage callables backed by the CPU oracle there).  That composed path renders
+band by band on exactly shifted coordinates (the operators keep the reference's signatures, which know nothing
+of shards); the HIP path (`ops=None`) is the fused frame with kernel-level row ownership.
 """
 from __future__ import annotations
 
+from dataclasses import dataclass
+from functools import lru_cache
 from types import SimpleNamespace
-from typing import Optional, Tuple
+from typing import List, Optional, Tuple
 
 import torch
 import torch.distributed as dist
@@ -47,34 +55,120 @@ def strip_pixels(rank: int, world: int, image_height: int, tile_size: int) -> Tu
     return min(r0 * tile_size, image_height), min(r1 * tile_size, image_height)
 
 
+@dataclass(frozen=True)
+class RowShard:
+    """The tile rows of the full image one rank owns (mirrors GsRowShard, include/gsplat_hip.h).
+    period == 1: the contiguous strip [row_begin, row_end); period > 1: row ty is owned iff
+    (ty // band) % period == phase (row_begin = 0, row_end = all rows)."""
+    row_begin: int
+    row_end: int
+    band: int
+    period: int
+    phase: int
+    tile_size: int
+    image_height: int
+
+    def owns(self, ty: int) -> bool:
+        if not (self.row_begin <= ty < self.row_end):
+            return False
+        return self.period <= 1 or (ty // self.band) % self.period == self.phase
+
+    def rows(self) -> List[int]:
+        return list(_rows_of(self))
+
+    @property
+    def bands(self) -> List[Tuple[int, int]]:
+        """owned pixel-row bands [(y0, y1), ...] of the full image, ascending, maximal"""
+        return list(_bands_of(self))
+
+    @property
+    def local_height(self) -> int:
+        return sum(y1 - y0 for y0, y1 in self.bands)
+
+    @property
+    def local_rows(self) -> int:
+        return len(self.rows())
+
+
+@lru_cache(maxsize=256)
+def _rows_of(shard: RowShard) -> Tuple[int, ...]:
+    return tuple(ty for ty in range(shard.row_begin, shard.row_end) if shard.owns(ty))
+
+
+@lru_cache(maxsize=256)
+def _bands_of(shard: RowShard) -> Tuple[Tuple[int, int], ...]:
+    out: List[Tuple[int, int]] = []
+    for ty in _rows_of(shard):
+        y0, y1 = ty * shard.tile_size, min((ty + 1) * shard.tile_size, shard.image_height)
+        if out and out[-1][1] == y0:
+            out[-1] = (out[-1][0], y1)
+        else:
+            out.append((y0, y1))
+    return tuple(out)
+
+
+@lru_cache(maxsize=256)
+def shard_for(rank: int, world: int, image_height: int, tile_size: int, interleave: int = 0) -> RowShard:
+    """interleave = 0: balanced contiguous strips; interleave = b > 0: bands of b tile rows, band j -> rank j % world."""
+    rows = tile_rows(image_height, tile_size)
+    if interleave and world > 1:
+        return RowShard(0, rows, int(interleave), world, rank, tile_size, int(image_height))
+    r0, r1 = strip_rows(rank, world, rows)
+    return RowShard(r0, r1, max(rows, 1), 1, 0, tile_size, int(image_height))
+
+
+def owned_pixel_rows(bands) -> torch.Tensor:
+    """row indices (int64) of the full image covered by `bands`, in the order a shard's images hold them"""
+    if not bands:
+        return torch.empty((0,), dtype=torch.int64)
+    return torch.cat([torch.arange(y0, y1, dtype=torch.int64) for y0, y1 in bands])
+
+
+def _reduce_partial_gradients(colour: torch.Tensor, splat: torch.Tensor, group, wait_colour: bool = True):
+    """THE exchange step of a sharded frame, shared by the fused and the composed path so that every rank issues the
+    same collectives in the same order: sum over the ranks of the colour columns (V', C), then of the splat columns
+    (V', 7 [+2 depth features | +1 depth]), V' = max(V, 1).  Returns the handle of the second collective (or None)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return None
+    first = dist.all_reduce(colour, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    second = dist.all_reduce(splat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    if wait_colour:
+        first.wait()
+    return second
+
+
 class _AllReduceGrads(torch.autograd.Function):
-    """Identity in the forward; in the backward the gradients of all inputs are packed into one
-    buffer and summed over the process group with a single all-reduce."""
+    """Identity in the forward; in the backward the partial gradients of (gaussians2d, features, depths) are summed
+    over the process group with the two collectives of `_reduce_partial_gradients`."""
 
     @staticmethod
-    def forward(ctx, group, *tensors):
-        ctx.group = group
-        ctx.shapes = [t.shape for t in tensors]
-        return tuple(t.view_as(t) for t in tensors)
+    def forward(ctx, group, depth_cols, gaussians2d, features, depths):
+        ctx.group, ctx.depth_cols, ctx.channels = group, int(depth_cols), int(features.shape[1])
+        return gaussians2d.view_as(gaussians2d), features.view_as(features), depths.view_as(depths)
 
     @staticmethod
-    def backward(ctx, *grads):
-        ref = next(g for g in grads if g is not None)
-        rows = ref.shape[0]
-        widths = [int(torch.Size(s[1:]).numel()) if len(s) > 1 else 1 for s in ctx.shapes]
-        packed = torch.zeros((rows, sum(widths)), dtype=ref.dtype, device=ref.device)
-        col = 0
-        for g, w in zip(grads, widths):
-            if g is not None:
-                packed[:, col:col + w] = g.reshape(rows, w)
-            col += w
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1:
-            dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=ctx.group)
-        out, col = [], 0
-        for s, w in zip(ctx.shapes, widths):
-            out.append(packed[:, col:col + w].reshape(s).contiguous())
-            col += w
-        return (None, *out)
+    def backward(ctx, g_points, g_features, g_depths):
+        ref = next(g for g in (g_points, g_features, g_depths) if g is not None)
+        v = ref.shape[0]
+        rows = max(v, 1)
+        # the fused frame reduces (V', 7 + depth feature columns): [z, z^2] with render_depth, nothing otherwise.
+        # Here the depth gradient is already folded to one column; pad to the same width so shapes agree.
+        width = 7 + ctx.depth_cols
+        c = ctx.channels
+        colour = torch.zeros((rows, c), dtype=ref.dtype, device=ref.device)
+        splat = torch.zeros((rows, width), dtype=ref.dtype, device=ref.device)
+        if g_features is not None:
+            colour[:v] = g_features
+        if g_points is not None:
+            splat[:v, :7] = g_points
+        if g_depths is not None and ctx.depth_cols:
+            splat[:v, 7] = g_depths.reshape(-1)
+        second = _reduce_partial_gradients(colour, splat, ctx.group)
+        if second is not None:
+            second.wait()
+        g_d = splat[:v, 7:8].contiguous() if ctx.depth_cols else \
+            (g_depths if g_depths is not None else None)
+        return None, None, splat[:v, :7].contiguous(), colour[:v], g_d
 
 
 def default_ops() -> SimpleNamespace:
@@ -90,11 +184,14 @@ def default_ops() -> SimpleNamespace:
 def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams,
                              config: RasterConfig = RasterConfig(), use_sh: bool = False, render_depth: bool = False,
                              use_depth16: bool = False, group=None, rank: Optional[int] = None,
-                             world_size: Optional[int] = None, ops: Optional[SimpleNamespace] = None):
-    """Render this rank's strip of the frame.  Returns a `Rendering` whose image tensors cover rows
-    [y0, y1) of the full image (`rendering.strip == (y0, y1)`); after `.backward()` of a loss summed
-    over strips, every rank holds the full parameter gradients.  `point_visibility` / `point_heuristic` are this
-    strip's share: `reduce_point_statistics` sums them over the ranks."""
+                             world_size: Optional[int] = None, ops: Optional[SimpleNamespace] = None,
+                             interleave: int = 0):
+    """Render this rank's rows of the frame.  Returns a `Rendering` whose image tensors hold the owned pixel rows
+    of the full image in ascending order: `rendering.bands` lists them as [(y0, y1), ...] (`rendering.strip` is the
+    first band -- the whole share of a contiguous shard; index a full-size target with
+    `owned_pixel_rows(rendering.bands)`).  After `.backward()` of a loss summed over the ranks, every rank holds the
+    full parameter gradients.  `gaussians2d` is in full-image coordinates, identical on every rank.
+    `point_visibility` / `point_heuristic` are this rank's share: `reduce_point_statistics` sums them."""
     from .renderer import Rendering, compute_depth_variance
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -102,15 +199,21 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
         world_size = dist.get_world_size(group) if dist.is_initialized() else 1
     w, h = (int(x) for x in camera_params.image_size)
     ts = config.tile_size
-    y0, y1 = strip_pixels(rank, world_size, h, ts)
+    shard = shard_for(rank, world_size, h, ts, interleave)
+    bands = shard.bands
+
+    def tag(r):
+        object.__setattr__(r, "bands", bands)
+        object.__setattr__(r, "strip", bands[0] if bands else (min(shard.row_begin * ts, h),) * 2)
+        object.__setattr__(r, "shard", shard)
+        return r
 
     if ops is None:
         from .fused import fused_supported, render_fused
-        if y1 > y0 and fused_supported(gaussians, camera_params, use_sh, False):
-            # the fused frame (fused.py) on this rank's strip; its backward carries the all-reduce
-            r = render_fused(gaussians, camera_params, config, render_depth, use_depth16, strip=(y0, y1), group=group)
-            object.__setattr__(r, "strip", (y0, y1))
-            return r
+        if fused_supported(gaussians, camera_params, use_sh, False):
+            # the fused frame (fused.py) on this rank's rows; its backward carries the exchange step
+            return tag(render_fused(gaussians, camera_params, config, render_depth, use_depth16, shard=shard,
+                                    group=group))
         ops = default_ops()
 
     gaussians2d, depths, indexes, ndc_depths = ops.project_with_ndc(
@@ -123,44 +226,61 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
         features = gaussians.feature[indexes]
 
     # everything upstream of this point is replicated; gradients arriving here are partial sums
-    g2d_r, features_r, depths_r = _AllReduceGrads.apply(group, gaussians2d, features, depths)
-
-    strip_h = y1 - y0
-    if strip_h <= 0:  # more ranks than tile rows: this rank renders nothing but still joins the collective
-        zero = (g2d_r.sum() + features_r.sum() + depths_r.sum()) * 0.0
-        image = torch.zeros((0, w, features.shape[1]), dtype=features.dtype, device=features.device) + zero
-        r = Rendering(image=image, image_weight=image[..., 0].detach(), camera=camera_params, config=config,
-                      points_in_view=indexes, point_depth=depths, gaussians2d=gaussians2d)
-        object.__setattr__(r, "strip", (y0, y1))
-        return r
-
-    shift = torch.zeros((7,), dtype=g2d_r.dtype, device=g2d_r.device)
-    shift[1] = float(y0)
-    local2d = g2d_r - shift
+    g2d_r, features_r, depths_r = _AllReduceGrads.apply(group, 2 if render_depth else 0, gaussians2d, features,
+                                                        depths)
     raster_features = torch.cat([depths_r, depths_r ** 2, features_r], dim=1) if render_depth else features_r
+    F = raster_features.shape[1]
 
-    overlap_to_point, ranges = ops.map_to_tiles(local2d, ndc_depths, image_size=(w, strip_h), config=config,
-                                                use_depth16=use_depth16)
-    raster = ops.rasterize_with_tiles(local2d, raster_features, tile_overlap_ranges=ranges.view(-1, 2),
-                                      overlap_to_point=overlap_to_point, image_size=(w, strip_h), config=config)
-    image, img_depth, img_var = raster.image, None, None
+    # band by band on exactly shifted means (the origin is a multiple of the tile size): the reference-shaped
+    # operators know nothing of shards
+    images, weights, vis, heur, band_heur = [], [], None, None, []
+    for y0, y1 in bands:
+        shift = torch.zeros((7,), dtype=g2d_r.dtype, device=g2d_r.device)
+        shift[1] = float(y0)
+        local2d = g2d_r - shift
+        o2p, ranges = ops.map_to_tiles(local2d, ndc_depths, image_size=(w, y1 - y0), config=config,
+                                       use_depth16=use_depth16)
+        raster = ops.rasterize_with_tiles(local2d, raster_features, tile_overlap_ranges=ranges.view(-1, 2),
+                                          overlap_to_point=o2p, image_size=(w, y1 - y0), config=config)
+        images.append(raster.image)
+        weights.append(raster.image_weight)
+        if config.compute_visibility:
+            vis = raster.visibility if vis is None else vis + raster.visibility
+        if config.compute_point_heuristic:
+            band_heur.append(raster.point_heuristic)
+    if images:
+        image, weight = torch.cat(images, 0), torch.cat(weights, 0)
+    else:  # no row owned: an empty image that still hangs on the graph, so backward() joins the collectives
+        zero = (g2d_r.sum() + raster_features.sum()) * 0.0
+        image = torch.zeros((0, w, F), dtype=features.dtype, device=features.device) + zero
+        weight = torch.zeros((0, w), dtype=features.dtype, device=features.device)
+        if config.compute_visibility:
+            vis = torch.zeros((gaussians2d.shape[0],), dtype=features.dtype, device=features.device)
+        if config.compute_point_heuristic:
+            heur = torch.zeros((gaussians2d.shape[0], 2), dtype=features.dtype, device=features.device)
+    img_depth = img_var = None
     if render_depth:
-        img_depth, img_var = compute_depth_variance(image[..., :2], raster.image_weight)
+        img_depth, img_var = compute_depth_variance(image[..., :2], weight)
         image = image[..., 2:]
-    r = Rendering(image=image, image_weight=raster.image_weight, depth=img_depth, depth_var=img_var,
-                  camera=camera_params, config=config,
-                  point_visibility=raster.visibility if config.compute_visibility else None,
-                  point_heuristic=raster.point_heuristic if config.compute_point_heuristic else None,
-                  points_in_view=indexes, point_depth=depths, gaussians2d=gaussians2d)
-    object.__setattr__(r, "strip", (y0, y1))
+    if band_heur:
+        # filled in by each band's backward pass (reference function.py:48-59): one band -> that tensor; several ->
+        # reduce_point_statistics() sums them (after backward()), `point_heuristic` itself then holds the first band only
+        heur = band_heur[0]
+    r = tag(Rendering(image=image, image_weight=weight, depth=img_depth, depth_var=img_var,
+                         camera=camera_params, config=config, point_visibility=vis, point_heuristic=heur,
+                         points_in_view=indexes, point_depth=depths, gaussians2d=gaussians2d))
+    object.__setattr__(r, "band_heuristics", band_heur)
     return r
 
 
 def reduce_point_statistics(rendering, group=None):
-    """`point_visibility` / `point_heuristic` of a sharded rendering cover this rank's strip only (they are sums
+    """`point_visibility` / `point_heuristic` of a sharded rendering cover this rank's rows only (they are sums
     over pixels).  Returns (visibility, heuristic) summed over the ranks -- one small all-reduce of (V,3) floats,
     to be called after `.backward()` (the heuristic is filled in by the backward pass); None where not computed."""
     vis, heur = rendering.point_visibility, rendering.point_heuristic
+    bands = getattr(rendering, "band_heuristics", None)
+    if bands and len(bands) > 1:
+        heur = torch.stack([b.detach() for b in bands]).sum(0)
     parts = [t.reshape(t.shape[0], -1) for t in (vis, heur) if t is not None]
     if not parts:
         return None, None
@@ -172,15 +292,20 @@ def reduce_point_statistics(rendering, group=None):
     return out_vis, out_heur
 
 
-def gather_image(strip_image: torch.Tensor, image_height: int, tile_size: int, group=None) -> torch.Tensor:
-    """All-gather the strips into the full (H, W, C) image on every rank (only when a caller needs it)."""
+def gather_image(shard_image: torch.Tensor, image_height: int, tile_size: int, group=None,
+                 interleave: int = 0) -> torch.Tensor:
+    """All-gather the ranks' rows into the full (H, W, C) image on every rank (only when a caller needs it)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
-        return strip_image
-    heights = [strip_pixels(r, world, image_height, tile_size) for r in range(world)]
-    max_h = max(b - a for a, b in heights)
-    pad = torch.zeros((max_h, *strip_image.shape[1:]), dtype=strip_image.dtype, device=strip_image.device)
-    pad[:strip_image.shape[0]] = strip_image
+        return shard_image
+    shards = [shard_for(r, world, image_height, tile_size, interleave) for r in range(world)]
+    max_h = max(s.local_height for s in shards)
+    pad = torch.zeros((max_h, *shard_image.shape[1:]), dtype=shard_image.dtype, device=shard_image.device)
+    pad[:shard_image.shape[0]] = shard_image
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
-    return torch.cat([p[:b - a] for p, (a, b) in zip(parts, heights)], dim=0)
+    full = torch.empty((image_height, *shard_image.shape[1:]), dtype=shard_image.dtype, device=shard_image.device)
+    for p, s in zip(parts, shards):
+        rows = owned_pixel_rows(s.bands).to(full.device)
+        full[rows] = p[:rows.shape[0]]
+    return full

@@ -26,6 +26,7 @@ class _ProjectFunction(torch.autograd.Function):
     """forward: gs_project_fwd (project + cull + compact + ndc depth); backward: gs_project_bwd."""
 
     @staticmethod
+    @nv.on_tensor_device
     def forward(ctx, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, image_size,
                 depth_range, config: RasterConfig):
         nv.require_device(position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
@@ -47,7 +48,7 @@ class _ProjectFunction(torch.autograd.Function):
         nv.check(lib.gs_project_fwd(n, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
                                     nv.ptr(T), nv.ptr(proj), int(image_size[0]), int(image_size[1]),
                                     float(depth_range[0]), float(depth_range[1]), cfg, nv.ptr(points), nv.ptr(depth),
-                                    nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of), nv.ptr(count), None, 0, 0.0,
+                                    nv.ptr(ndc), nv.ptr(indexes), nv.ptr(slot_of), nv.ptr(count), None, 0,
                                     None, nv.ptr(scratch), nbytes, nv.stream()), "gs_project_fwd")
         v = int(count.item())  # the one host sync of the stage (the reference's torch.nonzero, :146)
         points, depth, ndc, indexes = points[:v], depth[:v], ndc[:v], indexes[:v]
@@ -60,6 +61,7 @@ class _ProjectFunction(torch.autograd.Function):
         return points, depth, indexes, ndc
 
     @staticmethod
+    @nv.on_tensor_device
     def backward(ctx, dpoints, ddepth, _dindexes, _dndc):
         position, log_scaling, rotation, alpha_logit, T, proj, slot_of = ctx.saved_tensors
         lib = nv.lib()

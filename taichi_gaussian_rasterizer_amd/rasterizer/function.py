@@ -25,6 +25,7 @@ RasterOut = NamedTuple('RasterOut', [
 
 class _RasterFunction(torch.autograd.Function):
     @staticmethod
+    @nv.on_tensor_device
     def forward(ctx, gaussians, features, overlap_to_point, tile_overlap_ranges, image_size, config: RasterConfig):
         nv.require_device(gaussians, features, what="rasterize_with_tiles")
         nv.require_device(overlap_to_point, tile_overlap_ranges, dtype=torch.int32, what="rasterize_with_tiles tiles")
@@ -44,7 +45,7 @@ class _RasterFunction(torch.autograd.Function):
                else torch.empty((0,), dtype=torch.float32, device=dev))
         nv.check(lib.gs_raster_fwd(v, F, nv.ptr(g), nv.ptr(f), nv.ptr(ranges), nv.ptr(o2p), o2p.shape[0], w, h,
                                    nv.make_config(config), None, None, nv.ptr(image), nv.ptr(alpha),
-                                   nv.ptr(vis) if want_vis else None, nv.stream()), "gs_raster_fwd")
+                                   nv.ptr(vis) if want_vis else None, None, nv.stream()), "gs_raster_fwd")
         if not config.compute_visibility:
             vis_out = torch.empty((0,), dtype=torch.float32, device=dev) if not want_vis else vis
         else:
@@ -56,6 +57,7 @@ class _RasterFunction(torch.autograd.Function):
         return image, alpha, heur, vis_out
 
     @staticmethod
+    @nv.on_tensor_device
     def backward(ctx, grad_image, _ga, _gh, _gv):
         g, f, o2p, ranges, image = ctx.saved_tensors
         lib = nv.lib()
@@ -68,7 +70,7 @@ class _RasterFunction(torch.autograd.Function):
         rows = torch.zeros((v, row), dtype=torch.float32, device=g.device)
         nv.check(lib.gs_raster_bwd(v, F, nv.ptr(g), nv.ptr(f), nv.ptr(ranges), nv.ptr(o2p), o2p.shape[0], w, h,
                                    nv.make_config(config), None, None, nv.ptr(image), nv.ptr(gi), nv.ptr(rows),
-                                   nv.stream()), "gs_raster_bwd")
+                                   None, nv.stream()), "gs_raster_bwd")
         grad_g = torch.empty_like(g)
         grad_f = torch.empty_like(f)
         heur = ctx.heur if config.compute_point_heuristic else None

@@ -190,14 +190,20 @@ def render_projected(indexes: torch.Tensor, gaussians2d: torch.Tensor, features:
     if ndc_depths is None:
         ndc_depths = ndc_depth(depths.detach(), camera_params.near_plane, camera_params.far_plane)
     channels = features
+    raster_config = config
     if render_depth:  # two leading channels carry z and z^2 through the blend
         z = ndc_depths if use_ndc_depth else depths
         channels = torch.cat((z, z * z, features), dim=1)
+        if not use_ndc_depth:
+            # what the forward's early stop drops is bounded by forward_cut * max|feature|, and z^2 reaches far^2
+            # (data_types.RasterConfig.forward_cut; the fused frame applies the same scale)
+            raster_config = dataclasses.replace(
+                config, forward_cut=config.forward_cut / max(float(camera_params.far_plane) ** 2, 1.0))
 
     overlap_to_point, tile_ranges = map_to_tiles(gaussians2d, ndc_depths, image_size=size, config=config,
                                                  use_depth16=use_depth16)
     tiles = dict(tile_overlap_ranges=tile_ranges.view(-1, 2), overlap_to_point=overlap_to_point, image_size=size)
-    raster = rasterize_with_tiles(gaussians2d, channels, config=config, **tiles)
+    raster = rasterize_with_tiles(gaussians2d, channels, config=raster_config, **tiles)
 
     median = None
     if render_median_depth:  # first splat that takes a pixel past half opacity, no blending

@@ -24,6 +24,7 @@ def check_sh_degree(sh_features):
 
 class _SHFunction(torch.autograd.Function):
     @staticmethod
+    @nv.on_tensor_device
     def forward(ctx, params, points, indexes, camera_pos, degree, unique, slot_of):
         nv.require_device(params, points, camera_pos, what="evaluate_sh_at")
         nv.require_device(indexes, dtype=torch.int64, what="evaluate_sh_at indexes")
@@ -37,6 +38,7 @@ class _SHFunction(torch.autograd.Function):
         return out
 
     @staticmethod
+    @nv.on_tensor_device
     def backward(ctx, doutput):
         params, points, indexes, camera_pos, out = ctx.saved_tensors
         lib = nv.lib()

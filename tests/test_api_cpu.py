@@ -203,3 +203,59 @@ def test_helper_modules_cpu():
         assert torch.equal(w.grad, torch.zeros(3))
         w.grad += 1
     assert torch.equal(w.grad, torch.full((3,), 7.0))
+
+
+def test_bench_launches_n_ranks_as_a_child_process():
+    """bench.py --gpus N without a launcher around it starts torch.distributed.run itself (child process, never exec)
+    and a rank whose WORLD_SIZE disagrees with --gpus refuses to print a line"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--steps", "7", "--warmup",
+                          "2", "--dry-run-launch"], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    cmd = out.stdout.strip().split()
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    tail = cmd[cmd.index(os.path.join(root, "bench.py")) + 1:]
+    assert tail[:6] == ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    # a mislabelled world is an error, not a 1-GPU number printed as n_gpus: 1
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=env2, timeout=300)
+    assert out.returncode != 0 and "refusing" in out.stderr and out.stdout.strip() == ""
+
+
+def test_device_guard_logic():
+    """every operator runs on the device of its tensors (nv.on_tensor_device) and refuses tensors of one call that
+    live on different devices (nv.check_same_device) -- pure host logic, checked with stand-in tensors"""
+    import pytest
+    import torch
+    from taichi_gaussian_rasterizer_amd import _native as nv
+
+    class Fake:
+        is_cuda = True
+
+        def __init__(self, index):
+            self.device = torch.device("cuda", index)
+
+    nv.check_same_device([Fake(1), None, Fake(1), torch.zeros(2)])  # CPU tensors are judged elsewhere
+    with pytest.raises(RuntimeError, match="different devices"):
+        nv.check_same_device([Fake(0), Fake(1)])
+    # no GPU tensor among the arguments: the wrapped function runs as is
+    assert nv.on_tensor_device(lambda a, b: a + b)(1, 2) == 3
+    assert nv.on_tensor_device(lambda t: t.sum().item())(torch.ones(3)) == 3.0
+
+
+def test_row_shard_matches_the_c_side_numbering():
+    """GsRowShard (include/gsplat_hip.h): local row of an owned tile row, period 1 and interleaved"""
+    from taichi_gaussian_rasterizer_amd import _native as nv, parallel
+    s = parallel.shard_for(1, 3, 250, 16, interleave=2)   # 16 tile rows, the last one partial
+    assert s.rows() == [2, 3, 8, 9, 14, 15] and s.local_height == 5 * 16 + (250 - 15 * 16)
+    assert s.bands == [(32, 64), (128, 160), (224, 250)]
+    c = nv.make_shard(s)._obj
+    assert (c.row_begin, c.row_end, c.band, c.period, c.phase) == (0, 16, 2, 3, 1)
+    s = parallel.shard_for(2, 3, 250, 16)
+    assert s.period == 1 and s.rows() == list(range(s.row_begin, s.row_end)) and s.bands[-1][1] == 250

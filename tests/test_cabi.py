@@ -48,12 +48,12 @@ def test_argument_errors_are_reported_not_crashed():
     """host-side validation runs before any launch, so it can be exercised without a GPU"""
     lib = _native.lib()
     cfg = _native.GsRasterConfig(tile_size=7, alpha_threshold=1 / 255.)
-    rc = lib.gs_raster_fwd(0, 3, None, None, None, None, 0, 16, 16, cfg, None, None, None, None, None, None)
+    rc = lib.gs_raster_fwd(0, 3, None, None, None, None, 0, 16, 16, cfg, None, None, None, None, None, None, None)
     assert rc == -2 and b"tile_size" in lib.gs_last_error()
     with pytest.raises(NotImplementedError):
         _native.check(rc, "gs_raster_fwd")
     cfg = _native.GsRasterConfig(tile_size=16, alpha_threshold=1 / 255.)
-    rc = lib.gs_raster_fwd(0, 99, None, None, None, None, 0, 16, 16, cfg, None, None, None, None, None, None)
+    rc = lib.gs_raster_fwd(0, 99, None, None, None, None, 0, 16, 16, cfg, None, None, None, None, None, None, None)
     assert rc == -2 and b"feature width" in lib.gs_last_error()
     rc = lib.gs_radix_sort_pairs(10, 3, None, None, None, None, 0, 8, None, 0, None)
     assert rc == -2

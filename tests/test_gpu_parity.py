@@ -152,8 +152,10 @@ def test_raster_forward_backward(seed, n, size, tile, F):
 @pytest.mark.parametrize("seed,n,size,tile,F", [(11, 3000, (200, 120), 16, 3), (12, 2000, (160, 96), 32, 5)])
 def test_raster_wave_region_variants(nb, seed, n, size, tile, F, monkeypatch):
     """the rasterizer picks 16x16, 16x8 or 8x8 pixel regions per wave from the grid size (gs_raster_sub_blocks);
-    GS_RASTER_NB forces each variant on the same scene: all must agree with the oracle"""
-    monkeypatch.setenv("GS_RASTER_NB", str(nb))
+    the per-call tuning field GsRasterConfig.tune_wave_sub_blocks forces each variant on the same scene: all must
+    agree with the oracle"""
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    monkeypatch.setitem(nv.TUNING, "wave_sub_blocks", int(nb))
     g2d, depth, feat = pu.make_2d_scene(seed, n, size, channels=F, scale_factor=0.5)
     cfg = RasterConfig(tile_size=tile, compute_visibility=(nb == 2))
     ocfg = orc.OracleConfig.of(cfg)
@@ -476,6 +478,7 @@ def test_sharded_strips_on_one_gpu(world):
         gr = g.to(DEV).requires_grad_(True)
         rr = parallel.render_gaussians_sharded(gr, cam, cfg, use_sh=True, rank=rank, world_size=world)
         y0, y1 = rr.strip
+        assert rr.bands == [(y0, y1)] and torch.equal(rr.gaussians2d, r.gaussians2d)
         (rr.image * gi[y0:y1]).sum().backward()
         strips.append(rr.image.detach())
         grads = {k: v.grad.clone() for k, v in gr.items()}
@@ -710,7 +713,8 @@ def test_fused_frame_splits_heavy_tiles(nb, monkeypatch):
     feats = gs.evaluate_sh_at(b.feature, b.position.detach(), idx, cam.camera_position)
     r2 = render_projected(idx, g2d, feats, depths, cam, cfg, render_depth=False, ndc_depths=ndc)
     (r2.image * gi).sum().backward()
-    monkeypatch.setenv("GS_RASTER_NB", nb)
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    monkeypatch.setitem(nv.TUNING, "wave_sub_blocks", int(nb))
     a = g.to(DEV).requires_grad_(True)
     r = gs.render_gaussians(a, cam, cfg, use_sh=True)
     (r.image * gi).sum().backward()

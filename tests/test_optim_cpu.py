@@ -112,3 +112,32 @@ def test_reference_named_optim_modules_import_and_refuse_host_tensors():
     with optim.restore_grad(p):
         assert float(p.grad.abs().sum()) == 0.0
     assert float(p.grad.sum()) == 18.0
+
+
+def test_optimizer_state_uses_the_reference_checkpoint_keys():
+    """reference optim/util.py:5-18: FIRST moment (N, D) under 'v', SECOND moment under 'm' ((N) for vector groups).
+    A reference-layout state dict must load unchanged; a foreign layout must be refused before any kernel indexes
+    past the end of a buffer."""
+    from taichi_gaussian_rasterizer_amd.optim import fractional, util
+    n, d = 6, 3
+    p = torch.nn.Parameter(torch.randn(n, d))
+    p.grad = torch.randn(n, d)
+    # the accessor modules create exactly the reference's layout
+    st = {}
+    first, second = util.get_vector_state(st, p)
+    assert first is st["v"] and second is st["m"] and first.shape == (n, d) and second.shape == (n,)
+    st = {}
+    first, second = util.get_scalar_state(st, p)
+    assert first is st["v"] and second is st["m"] and first.shape == second.shape == (n, d)
+    # a reference checkpoint of a vector group: 'v' (N, D), 'm' (N) -> picked up as (first, second) without translation
+    ref_state = {p: {"v": torch.full((n, d), 2.0), "m": torch.full((n,), 3.0)}}
+    rows = fractional._Rows(dict(params=[p], name="p", type="vector", lr=0.1, betas=(0.9, 0.999), eps=1e-16,
+                                 bias_correction=True, mask_lr=None, point_lr=None), ref_state)
+    m, v = rows.moments()
+    assert m is ref_state[p]["v"] and v is ref_state[p]["m"]
+    # the swapped layout ((N) under 'v') is refused by the shape check, not handed to the kernel
+    bad = {p: {"v": torch.zeros(n), "m": torch.zeros(n, d)}}
+    rows = fractional._Rows(dict(params=[p], name="p", type="vector", lr=0.1, betas=(0.9, 0.999), eps=1e-16,
+                                 bias_correction=True, mask_lr=None, point_lr=None), bad)
+    with pytest.raises(AssertionError, match="first moment"):
+        fractional._launch(rows, 0, torch.arange(n), torch.ones(n), torch.zeros(n), p.grad, None, in_place=True)

@@ -168,7 +168,7 @@ def test_parameter_class_prune_and_split_in_the_fit_loop():
 
     params, first, raster = epoch(params, 12)
     rows = int(params.batch_size[0])
-    moment = params.tensor_state["feature"]["m"].clone()
+    moment = params.tensor_state["feature"]["v"].clone()  # first moment: key 'v' (reference optim/util.py:5-18)
     prune = torch.topk(raster.visibility, k=rows // 10, largest=False).indices
     split = torch.topk(raster.point_heuristic[:, 1], k=rows // 10).indices
     split = split[~torch.isin(split, prune)]
@@ -180,7 +180,7 @@ def test_parameter_class_prune_and_split_in_the_fit_loop():
     params = params[keep.nonzero().squeeze(1)].append_tensors(dict(children.items()))
     expect = rows - prune.shape[0] - split.shape[0] + 2 * split.shape[0]
     assert int(params.batch_size[0]) == expect
-    kept = params.tensor_state["feature"]["m"]
+    kept = params.tensor_state["feature"]["v"]
     assert kept.shape[0] == expect and torch.equal(kept[:int(keep.sum())], moment[keep])
     assert torch.equal(kept[int(keep.sum()):], torch.zeros_like(kept[int(keep.sum()):]))
     params, second, _ = epoch(params, 12)

@@ -27,7 +27,7 @@ def _scene(size, n, depth_mode):
     return g, cam, gi, gdm
 
 
-def _run(rank, world, port, size, n, depth_mode, out_dir):
+def _run(rank, world, port, size, n, depth_mode, interleave, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -35,25 +35,32 @@ def _run(rank, world, port, size, n, depth_mode, out_dir):
         g, cam, gi, gdm = _scene(size, n, depth_mode)
         g = g.requires_grad_(True)
         cfg = RasterConfig(compute_visibility=True, compute_point_heuristic=True)
-        r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode, ops=oracle_ops.OPS)
-        y0, y1 = r.strip
-        loss = (r.image * gi[y0:y1]).sum()
+        r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode, ops=oracle_ops.OPS,
+                                              interleave=interleave)
+        rows = parallel.owned_pixel_rows(r.bands)
+        assert r.image.shape[0] == rows.shape[0] == r.shard.local_height
+        loss = (r.image * gi[rows]).sum()
         if depth_mode:
-            loss = loss + (r.depth * gdm[y0:y1]).sum()
+            loss = loss + (r.depth * gdm[rows]).sum()
         loss.backward()
-        full = parallel.gather_image(r.image.detach(), size[1], cfg.tile_size)
+        full = parallel.gather_image(r.image.detach(), size[1], cfg.tile_size, interleave=interleave)
         vis, heur = parallel.reduce_point_statistics(r)
-        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=full.numpy(), strip=np.array([y0, y1]),
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=full.numpy(), rows=rows.numpy(),
                  vis=vis.numpy(), heur=heur.numpy(),
                  **{f"d_{k}": v.grad.numpy() for k, v in g.items()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,size,n,depth_mode", [(2, (96, 80), 1500, False), (3, (64, 112), 800, True)])
-def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_mode):
+@pytest.mark.parametrize("world,size,n,depth_mode,interleave", [
+    (2, (96, 80), 1500, False, 0), (3, (64, 112), 800, True, 0),
+    (2, (96, 80), 1500, False, 1),     # interleaved: single tile rows dealt round-robin
+    (3, (64, 112), 800, True, 2),      # bands of two tile rows, the last band partial
+    (3, (64, 30), 400, True, 0),       # more ranks than tile rows: rank 2 owns nothing and still joins the collectives
+])
+def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_mode, interleave):
     port = _free_port()
-    mp.spawn(_run, args=(world, port, size, n, depth_mode, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, port, size, n, depth_mode, interleave, str(tmp_path)), nprocs=world, join=True)
 
     g, cam, gi, gdm = _scene(size, n, depth_mode)
     g = g.requires_grad_(True)
@@ -67,7 +74,7 @@ def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_m
     covered = []
     for rank in range(world):
         z = np.load(tmp_path / f"rank{rank}.npz")
-        covered.append(tuple(z["strip"]))
+        covered.append(z["rows"])
         # strips are rendered by the same arithmetic on exactly shifted coordinates
         assert np.allclose(z["image"], r.image.detach().numpy(), rtol=0, atol=1e-6)
         # per-strip visibility / heuristics summed over the ranks = the single-process statistics
@@ -76,8 +83,8 @@ def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_m
         for k, v in g.items():
             ref = v.grad.numpy()
             assert np.allclose(z[f"d_{k}"], ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(ref).max())), (rank, k)
-    assert covered[0][0] == 0 and covered[-1][1] == size[1]
-    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    # the ranks' rows partition the image
+    assert sorted(np.concatenate(covered).tolist()) == list(range(size[1]))
 
 
 def test_strip_partition():
@@ -88,3 +95,22 @@ def test_strip_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_row_shards_partition_the_tile_rows():
+    for world in (1, 2, 3, 8):
+        for height, ts in ((16, 16), (100, 16), (2048, 16), (129, 8), (30, 16)):
+            rows = parallel.tile_rows(height, ts)
+            for interleave in (0, 1, 2, 5):
+                shards = [parallel.shard_for(r, world, height, ts, interleave) for r in range(world)]
+                owned = sorted(ty for s in shards for ty in s.rows())
+                assert owned == list(range(rows)), (world, height, ts, interleave)
+                assert sum(s.local_height for s in shards) == height
+                px = sorted(int(y) for s in shards for y in parallel.owned_pixel_rows(s.bands))
+                assert px == list(range(height))
+                for s in shards:  # local row numbering = position in the ascending list of owned rows
+                    for local, ty in enumerate(s.rows()):
+                        if s.period > 1:
+                            assert (ty // (s.band * s.period)) * s.band + ty % s.band == local
+                        else:
+                            assert ty - s.row_begin == local

@@ -27,7 +27,7 @@ def _scene(size, n):
     return g, cam, gi, gd
 
 
-def _run(rank, world, port, size, n, depth_mode, out_dir):
+def _run(rank, world, port, size, n, depth_mode, interleave, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
@@ -37,25 +37,29 @@ def _run(rank, world, port, size, n, depth_mode, out_dir):
         g = g.to(dev).requires_grad_(True)
         cam = cam.to(device=dev)
         cfg = RasterConfig()
-        r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode)
-        y0, y1 = r.strip
-        loss = (r.image * gi.to(dev)[y0:y1]).sum()
+        r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode,
+                                              interleave=interleave)
+        rows = parallel.owned_pixel_rows(r.bands).to(dev)
+        loss = (r.image * gi.to(dev)[rows]).sum()
         if depth_mode:
-            loss = loss + (r.depth * gd.to(dev)[y0:y1]).sum()
+            loss = loss + (r.depth * gd.to(dev)[rows]).sum()
         loss.backward()
-        full = parallel.gather_image(r.image.detach(), size[1], cfg.tile_size)
+        full = parallel.gather_image(r.image.detach(), size[1], cfg.tile_size, interleave=interleave)
         np.savez(os.path.join(out_dir, f"rank{rank}.npz"), image=full.cpu().numpy(),
                  **{f"d_{k}": v.grad.cpu().numpy() for k, v in g.items()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("depth_mode", [False, True])
-def test_fused_sharded_frame_two_ranks(tmp_path, depth_mode):
+@pytest.mark.parametrize("depth_mode,interleave,world,size", [(False, 0, 2, (320, 256)), (True, 0, 2, (320, 256)),
+                                                              (False, 2, 2, (320, 250)),
+                                                              (True, 0, 3, (320, 30))])  # rank 2 owns no tile row
+def test_fused_sharded_frame_two_ranks(tmp_path, depth_mode, interleave, world, size):
     import taichi_gaussian_rasterizer_amd as gs
     from taichi_gaussian_rasterizer_amd import RasterConfig
-    world, size, n = 2, (320, 256), 20000
-    mp.spawn(_run, args=(world, _free_port(), size, n, depth_mode, str(tmp_path)), nprocs=world, join=True)
+    n = 20000
+    mp.spawn(_run, args=(world, _free_port(), size, n, depth_mode, interleave, str(tmp_path)), nprocs=world,
+             join=True)
     dev = torch.device("cuda:0")
     g, cam, gi, gd = _scene(size, n)
     g = g.to(dev).requires_grad_(True)

@@ -16,7 +16,7 @@ for n, size in cases:
     tiles = -(-size[0] // 16) * -(-size[1] // 16)
     line = f"n={n:8d} {size[0]}x{size[1]} tiles={tiles:6d}:"
     for nb in (1, 2, 4):
-        os.environ["GS_RASTER_NB"] = str(nb)
+        nv.TUNING["wave_sub_blocks"] = int(nb)
         def step():
             for _, t in gg.items(): t.grad = None
             r = gs.render_gaussians(gg, cam, cfg, use_sh=True)

@@ -5,18 +5,23 @@ import torch
 import taichi_gaussian_rasterizer_amd as gs
 from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, parallel, _native as nv
 wl = sys.argv[1] if len(sys.argv) > 1 else "c3"
+interleave = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 n, size = (1_000_000, (2048, 2048)) if wl == "c3" else (6_000_000, (4096, 4096))
 g, cam = scenes.benchmark_scene(n, size, sh_degree=3, seed=0)
 cam = cam.to(device='cuda:0'); cfg = RasterConfig()
 G = torch.rand(size[1], size[0], 3, device='cuda:0')
 gg = g.to('cuda:0').requires_grad_(True)
+rows_of = {}
+base = None
 for world in (1, 2, 4, 8):
     rank = world // 2
     def step():
         for _, t in gg.items(): t.grad = None
-        r = parallel.render_gaussians_sharded(gg, cam, cfg, use_sh=True, rank=rank, world_size=world)
-        y0, y1 = r.strip
-        r.image.backward(G[y0:y1])
+        r = parallel.render_gaussians_sharded(gg, cam, cfg, use_sh=True, rank=rank, world_size=world,
+                                              interleave=interleave)
+        if world not in rows_of:
+            rows_of[world] = G[parallel.owned_pixel_rows(r.bands).cuda()].contiguous()
+        r.image.backward(rows_of[world])
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(20): step()
@@ -25,4 +30,5 @@ for world in (1, 2, 4, 8):
     for _ in range(5): step()
     torch.cuda.synchronize(); nv.timer.enabled = False
     st = {k: round(v[1] / 5, 3) for k, v in nv.timer.summary().items()}
-    print(f"world {world} rank {rank}: {dt:.3f} ms/frame (no collective) ", st)
+    base = base or dt
+    print(f"world {world} rank {rank}: {dt:.3f} ms/frame (no collective), {base / dt:.2f}x of one GPU ", st)

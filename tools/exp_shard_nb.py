@@ -12,7 +12,7 @@ for world in (2, 4, 8, 16):
     rank = world // 2
     line = f"world {world:2d} (tiles {128 * 128 // world:5d}):"
     for nb in ("1", "2", "4"):
-        os.environ["GS_RASTER_NB"] = nb
+        nv.TUNING["wave_sub_blocks"] = int(nb)
         def step():
             for _, t in gg.items(): t.grad = None
             r = parallel.render_gaussians_sharded(gg, cam, cfg, use_sh=True, rank=rank, world_size=world)

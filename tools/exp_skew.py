@@ -19,7 +19,7 @@ cam = cam.to(device='cuda:0'); cfg = RasterConfig()
 G = torch.rand(size[1], size[0], 3, device='cuda:0')
 gg = g.to('cuda:0').requires_grad_(True)
 for heavy in ("1", "0"):
-    os.environ["GS_RASTER_HEAVY"] = heavy
+    nv.TUNING["no_heavy_split"] = 1 if heavy == "0" else 0
     def step():
         for _, t in gg.items(): t.grad = None
         r = gs.render_gaussians(gg, cam, cfg, use_sh=True)
