@@ -717,8 +717,12 @@ ORC_PROJECT(f64, double)
 // margin[pixel] = min over the tile's splats of |alpha_p * pdf - thr| / thr, evaluated in f32 exactly as raster_fwd
 // does.  A pixel on which two correct f32 implementations disagree by more than rounding must have a tiny margin:
 // the only discontinuity of the forward is that comparison, and one flip moves the pixel by <= thr * |feature|.
-void orc_raster_flip_margin_f32(const float* points, const int32_t* ranges, const int32_t* o2p, int W, int H,
-                                const RasterCfg* cfg, float* margin) {
+// feat_max (optional, (H, W, F)): per pixel and channel, the largest |feature| among the splats it blends -- the scale
+// of the absolute rounding error of a blend (the accumulated weight carries ~1e-6 of absolute error whatever the
+// features are, so a z^2 channel reaching 1e4 cannot be held to the absolute tolerance of a colour in [0, 1]).
+void orc_raster_flip_margin_f32(const float* points, const float* features, int F, const int32_t* ranges,
+                                const int32_t* o2p, int W, int H, const RasterCfg* cfg, float* margin,
+                                float* feat_max) {
   const int ts = cfg->tile_size;
   const int tw = (W + ts - 1) / ts, th = (H + ts - 1) / ts;
   const float thr = float(cfg->alpha_threshold);
@@ -730,10 +734,15 @@ void orc_raster_flip_margin_f32(const float* points, const int32_t* ranges, cons
       for (int px = tx0; px < std::min(tx0 + ts, W); ++px) {
         const float pxf = float(px) + 0.5f, pyf = float(py) + 0.5f;
         float best = 1e30f;
+        float* fm = feat_max ? feat_max + (int64_t(py) * W + px) * F : nullptr;
+        for (int c = 0; fm && c < F; ++c) fm[c] = 0.0f;
         for (int k = start; k < end; ++k) {
           const float* g = points + int64_t(o2p[k]) * 7;
           const float a = g[6] * (cfg->antialias ? pdf_aa<float>(pxf, pyf, g) : pdf_plain<float>(pxf, pyf, g));
           best = std::min(best, std::fabs(a - thr) / thr);
+          // largest feature magnitude among the splats that can reach this pixel's blend (margin included)
+          if (fm && a > thr * 0.999f)
+            for (int c = 0; c < F; ++c) fm[c] = std::max(fm[c], std::fabs(features[int64_t(o2p[k]) * F + c]));
         }
         margin[int64_t(py) * W + px] = best;
       }

@@ -290,7 +290,8 @@ def rasterize_backward(gaussians2d, features, overlap_to_point, tile_overlap_ran
     return gg, gf, (heur if cfg.compute_point_heuristic else None)
 
 
-def raster_flip_margin(gaussians2d, overlap_to_point, tile_overlap_ranges, image_size, config=OracleConfig()):
+def raster_flip_margin(gaussians2d, overlap_to_point, tile_overlap_ranges, image_size, config=OracleConfig(),
+                       features=None):
     """(H, W) f32: per pixel, min over its tile's splats of |alpha - alpha_threshold| / alpha_threshold (diagnostic
     used by the parity tests to prove that an out-of-tolerance pixel is an `alpha > threshold` decision two f32
     implementations round to different sides, forward.py:100)."""
@@ -300,8 +301,15 @@ def raster_flip_margin(gaussians2d, overlap_to_point, tile_overlap_ranges, image
     W, H = int(image_size[0]), int(image_size[1])
     margin = np.empty((H, W), np.float32)
     c = cfg.c_struct()
-    lib().orc_raster_flip_margin_f32(_p(g), _p(rng), _p(o2p), W, H, ctypes.byref(c), _p(margin))
-    return margin
+    if features is None:
+        lib().orc_raster_flip_margin_f32(_p(g), None, 0, _p(rng), _p(o2p), W, H, ctypes.byref(c), _p(margin), None)
+        return margin
+    # with features: also (H, W, F), per pixel and channel the largest |feature| among the splats it blends
+    f = _np(features, np.float32)
+    feat_max = np.empty((H, W, f.shape[1]), np.float32)
+    lib().orc_raster_flip_margin_f32(_p(g), _p(f), int(f.shape[1]), _p(rng), _p(o2p), W, H, ctypes.byref(c),
+                                     _p(margin), _p(feat_max))
+    return margin, feat_max
 
 
 def rasterize(gaussians2d, depth, features, image_size, config=OracleConfig(), use_depth16=False):

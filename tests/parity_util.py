@@ -60,6 +60,52 @@ def assert_rows_close(hip, ref, name, tol=5e-2, frac=0.995):
     assert ok.mean() >= frac, f"{name}: only {ok.mean():.4f} of rows within {tol} (need {frac})"
 
 
+# End-to-end (GPU pipeline vs CPU pipeline, nothing shared) row-wise bar.  Two things make single rows differ by more
+# than rounding in ANY pair of f32 implementations, and both were measured (tools/diag_e2e_rows.py):
+#   * the eigen-decomposition adjoint divides by the eigenvalue gap of the projected covariance: rows whose relative
+#     gap (l1 - l2) / (l1 + l2) is below GAP_EXCLUDE are left out -- 0.7 % - 1.2 % of the visible rows on the test
+#     scenes, asserted to stay below MAX_GAP_EXCLUDED;
+#   * discrete decisions downstream of the projection -- alpha > threshold at a pixel, W >= saturate_threshold, the depth
+#     order of two splats with nearly equal depth -- fall differently once the projected means differ in the last bit;
+#     a flipped decision changes a small splat's gradient by whole percents (its position gradient is a sum of
+#     cancelling terms).  Measured: 0.0 % - 0.30 % of the well-conditioned rows miss 1e-2, independent of the gap.
+# Hence: at least E2E_FRAC of the well-conditioned rows within E2E_TOL, and the MEDIAN row error (the bulk, untouched by
+# either effect) within E2E_MEDIAN.  (Round 1 had tol 5e-2 with a blanket 0.5 % of all rows unconstrained.)
+GAP_EXCLUDE = 0.03
+MAX_GAP_EXCLUDED = 0.02
+E2E_TOL = 1e-2
+E2E_FRAC = 0.996
+E2E_MEDIAN = 5e-5   # measured 3e-7 - 2e-5
+
+
+def relative_eigen_gap(points):
+    """(l1 - l2) / (l1 + l2) of the 2D covariance of packed gaussians (V, 7)"""
+    c = cov_form(points)
+    c00, c01, c11 = c[:, 2], c[:, 3], c[:, 4]
+    return np.sqrt((c00 - c11) ** 2 + 4 * c01 ** 2) / (c00 + c11)
+
+
+def assert_rows_close_e2e(hip, ref, relgap, name):
+    """relgap: per ROW of hip / ref (np.inf for rows without a projected splat)"""
+    hip, ref = to_np(hip).astype(np.float64), to_np(ref).astype(np.float64)
+    hip, ref = hip.reshape(hip.shape[0], -1), ref.reshape(ref.shape[0], -1)
+    assert np.isfinite(hip).all(), f"{name}: non-finite values"
+    visible = np.isfinite(relgap)
+    keep = relgap >= GAP_EXCLUDE
+    excluded = 1.0 - keep[visible].mean() if visible.any() else 0.0
+    assert excluded <= MAX_GAP_EXCLUDED, f"{name}: {excluded:.4f} of the visible rows have an eigenvalue gap < {GAP_EXCLUDE}"
+    err = np.linalg.norm(hip - ref, axis=1)
+    mag = np.linalg.norm(ref, axis=1)
+    floor = 1e-3 * float(np.median(mag[mag > 0])) if (mag > 0).any() else 1e-20
+    rel = err / (mag + floor)
+    ok = rel[keep] <= E2E_TOL
+    med = float(np.median(rel[keep & visible])) if (keep & visible).any() else 0.0
+    assert ok.mean() >= E2E_FRAC, (f"{name}: only {ok.mean():.5f} of the well-conditioned rows within {E2E_TOL} "
+                                   f"(need {E2E_FRAC}; {excluded:.4f} excluded for their eigenvalue gap)")
+    assert med <= E2E_MEDIAN, f"{name}: median row error {med:.3e} > {E2E_MEDIAN}"
+    return dict(excluded_for_gap=float(excluded), within_tol=float(ok.mean()), median=med)
+
+
 def cov_form(points):
     """(mean.xy, cov00, cov01, cov11, alpha): well-conditioned form of the packed 2D gaussian."""
     p = to_np(points).astype(np.float64)

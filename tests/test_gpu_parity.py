@@ -440,9 +440,12 @@ def test_render_gaussians_end_to_end_vs_oracle(seed, n, size, deg, depth_mode):
     pu.assert_pixels_close(r.image, ref["image"], "image", atol=1e-3, rtol=1e-3)
     pu.assert_pixels_close(r.image_weight, ref["alpha"], "image_weight", atol=1e-3, rtol=1e-3)
     (r.image * dev(gi)).sum().backward()
+    relgap = np.full(n, np.inf)
+    relgap[ref["indexes"]] = pu.relative_eigen_gap(ref["points"])
     for name, key in (("position", "d_position"), ("log_scaling", "d_log_scaling"), ("rotation", "d_rotation"),
                       ("alpha_logit", "d_alpha_logit"), ("feature", "d_feature")):
-        pu.assert_rows_close(getattr(gd, name).grad, ref[key], f"grad {name}")
+        rep = pu.assert_rows_close_e2e(getattr(gd, name).grad, ref[key], relgap, f"grad {name}")
+        print(f"e2e seed {seed} {name}: {rep}")
 
 
 # ------------------------------------------------------------------- config 1 on the GPU path
