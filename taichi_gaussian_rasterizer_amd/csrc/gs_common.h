@@ -234,6 +234,34 @@ __device__ __forceinline__ float gs_wave_reduce_transposed(float (&v)[N], int la
   return d;
 }
 
+// Which of a wave region's NB 8x8 pixel sub-blocks can a splat reach?  (Ax, Ay), (Bx, By) are the rows of the map
+// d = pixel - mean  ->  t  in which alpha > alpha_threshold  <=>  |t|^2 < r2; (relx, rely) = first pixel centre of the
+// region minus the mean.  Per sub-block the EXACT minimum of the quadratic |t(d)|^2 over the block's 8x8 pixel centres
+// (a box): zero when the mean lies inside, otherwise attained on one of the two edges facing the mean, where it is a
+// clamped 1-D parabola vertex.  Bit b is set when that minimum is below r2 (plus rounding slack) -- unlike a test of
+// the ellipse's oriented bounding box this also drops the blocks that only the box's corners reach.
+// Runs once per (wave, splat) on the staging lane: ~20 VALU per sub-block spread over 64 splats.
+template <int NB>
+__device__ __forceinline__ int gs_sub_block_mask(float Ax, float Ay, float Bx, float By, float r2, float relx,
+                                                 float rely) {
+  const float sxx = Ax * Ax + Bx * Bx, sxy = Ax * Ay + Bx * By, syy = Ay * Ay + By * By;
+  const float rxy = -sxy / syy, ryx = -sxy / sxx;  // vertex of the parabola along an edge x = const / y = const
+  const float lim = r2 * 1.002f + 1e-3f;
+  int mask = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float xa = relx + float((b & 1) * 8), ya = rely + float((b >> 1) * 8);
+    const float xb = xa + 7.0f, yb = ya + 7.0f;
+    const float xn = __builtin_amdgcn_fmed3f(0.0f, xa, xb), yn = __builtin_amdgcn_fmed3f(0.0f, ya, yb);
+    const float ys = __builtin_amdgcn_fmed3f(rxy * xn, ya, yb);  // best y on the edge x = xn
+    const float xs = __builtin_amdgcn_fmed3f(ryx * yn, xa, xb);  // best x on the edge y = yn
+    const float q1 = sxx * xn * xn + 2.0f * sxy * xn * ys + syy * ys * ys;
+    const float q2 = sxx * xs * xs + 2.0f * sxy * xs * yn + syy * yn * yn;
+    if (fminf(q1, q2) <= lim) mask |= 1 << b;
+  }
+  return mask;
+}
+
 __device__ __forceinline__ float gs_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float gs_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
 

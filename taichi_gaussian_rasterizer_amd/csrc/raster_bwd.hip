@@ -108,14 +108,18 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   // which value of the per-splat reduction this lane ends up owning (lane-constant; -1 = none)
   const int my_slot = (NACC <= 16 && (lane & 3) == 0) ? gs_reduce_slot<(NACC <= 16 ? NACC : 1)>(lane) : -1;
   const int lx = lane & 7, ly = lane >> 3;
-  float Xf[NB], Yf[NB], Wt[NB], R[NB], gpix[NB][FP];
+  // Tr = 1 - (accumulated weight): the transmittance in front of the next splat.  The reference carries the weight W
+  // and tests W < saturate_threshold (backward.py:160); Tr > 1 - saturate_threshold is the same test, and every use of
+  // W in the gradient is through 1 - W.
+  const float tsat = 1.0f - a.sat;
+  float Xf[NB], Yf[NB], Tr[NB], R[NB], gpix[NB][FP];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
     const bool inb = X < a.W && Y < a.H;
     Xf[b] = float(X) + 0.5f;
     Yf[b] = float(Y) + 0.5f;
-    Wt[b] = inb ? 0.0f : 1.0f;  // backward.py:99-112: out-of-image pixels start saturated
+    Tr[b] = inb ? 1.0f : 0.0f;  // backward.py:99-112: out-of-image pixels start saturated
     R[b] = 0.0f;
 #pragma unroll
     for (int c = 0; c < FP; ++c) gpix[b][c] = 0.0f;
@@ -130,19 +134,25 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
     }
   }
 
-  const int2 range = a.ranges[tile];
+  const int2 range_v = a.ranges[tile];
+  // wave-uniform: keep the loop bounds in scalar registers
+  const int range_x = __builtin_amdgcn_readfirstlane(range_v.x), range_y = __builtin_amdgcn_readfirstlane(range_v.y);
+  // lean kernels stage the ellipse frame scaled by K_EXP so that the pdf is exp2(-(tx^2 + ty^2)) with no further
+  // multiply; the moments are accumulated in those coordinates and unscaled once per splat in the epilogue
+  constexpr float K_EXP = 0.84932180028801904f;  // sqrt(0.5 * log2(e))
+  constexpr float IK = 1.0f / K_EXP, IK2 = IK * IK;
 
-  for (int g0 = range.x; g0 < range.y; g0 += 64) {
+  for (int g0 = range_x; g0 < range_y; g0 += 64) {
     // all pixels of the region saturated -> nothing further contributes (backward.py:116-118)
     // ... and a saturated 8x8 sub-block takes no gradient from here on (:160,166): masked out before its alphas
     // are even computed
     int live = 0;
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-      if (__ballot(Wt[b] < a.sat) != 0ull) live |= 1 << b;
+      if (__ballot(Tr[b] > tsat) != 0ull) live |= 1 << b;
     if (live == 0) break;
 
-    const int cnt = min(64, range.y - g0);
+    const int cnt = __builtin_amdgcn_readfirstlane(min(64, range_y - g0));
     float ax = 0, ay = 0, isx = 0, isy = 0, al = 0;
     int idx = 0;
     if (lane < cnt) {
@@ -152,24 +162,15 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       ax = p[2]; ay = p[3];
       isx = 1.0f / p[4]; isy = 1.0f / p[5];
       al = p[6];
-      const float Ax = ax * isx, Ay = ay * isx, Bx = -ay * isy, By = ax * isy;
+      const float ks = FULL ? 1.0f : K_EXP;
+      const float Ax = ax * isx * ks, Ay = ay * isx * ks, Bx = -ay * isy * ks, By = ax * isy * ks;
       int mask = 0;
       if (FULL && a.aa) {
         mask = (1 << NB) - 1;
       } else if (al > a.thr) {
-        // alpha*exp(-0.5 (tx^2+ty^2)) > thr  needs  tx^2+ty^2 < 2 ln(alpha/thr)
-        const float r = sqrtf(2.0f * __logf(al / a.thr)) * 1.001f + 0.01f;
-        const float et = 3.5f * (fabsf(Ax) + fabsf(Ay)) + r, eb = 3.5f * (fabsf(Bx) + fabsf(By)) + r;
-        // plus the image axes: the ellipse's bounding box against the sub-block
-        const float sx = p[4], sy = p[5];
-        const float ex = 3.5f + r * sqrtf(ax * ax * sx * sx + ay * ay * sy * sy);
-        const float ey = 3.5f + r * sqrtf(ay * ay * sx * sx + ax * ax * sy * sy);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const float cx = float(x0 + (b & 1) * 8) + 4.0f - mx, cy = float(y0 + (b >> 1) * 8) + 4.0f - my;
-          if (fabsf(cx * Ax + cy * Ay) <= et && fabsf(cx * Bx + cy * By) <= eb && fabsf(cx) <= ex && fabsf(cy) <= ey)
-            mask |= 1 << b;
-        }
+        // alpha * pdf > thr  needs  tx^2 + ty^2 < log2(alpha / thr)  (scaled frame; 2 ln(alpha / thr) unscaled)
+        const float r2 = __log2f(al / a.thr) * (FULL ? 1.38629436111989f : 1.0f);
+        mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, r2, float(x0) + 0.5f - mx, float(y0) + 0.5f - my);
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
       s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
@@ -197,7 +198,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       for (int c = 0; c < NS; ++c) S[c] = 0.0f;
 #pragma unroll
       for (int c = 0; c < FP; ++c) gf[c] = 0.0f;
-      bool has_grad = false;
+      bool any_grad = false;  // wave-uniform: some pixel of some sub-block took a gradient from this splat
 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -227,7 +228,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         } else {
           tx = dx * g0v.z + dy * g0v.w;
           ty = dx * g1v.x + dy * g1v.y;
-          p = gs_exp2_fast(-0.72134752044448170f * (tx * tx + ty * ty));
+          p = FULL ? gs_exp2_fast(-0.72134752044448170f * (tx * tx + ty * ty)) : gs_exp2_fast(-(tx * tx + ty * ty));
           if (FULL) {
             // taichi_lib/generic.py:321-336
             const float txs = tx * g2v.z, tys = ty * g2v.w;
@@ -240,19 +241,23 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           }
         }
         const float alpha_raw = g1v.z * p;
-        const bool hit = alpha_raw > a.thr && Wt[b] < a.sat;  // backward.py:160,166
+        const bool hit = alpha_raw > a.thr && Tr[b] > tsat;  // backward.py:160,166
         if (__ballot(hit) == 0ull) continue;
-        has_grad |= hit;
-        const float alc = __builtin_amdgcn_fmed3f(alpha_raw, a.cmax, -1.0f);  // min(alpha, cmax), one v_med3_f32 (:169)
-        const float T = 1.0f - Wt[b];
-        const float w = hit ? alc * T : 0.0f;
+        any_grad = true;
+        // everything below is linear in a_hit (= 0 where the pixel takes nothing from this splat), so one select does
+        // for the weight, the feature gradients and the moments
+        const float a_hit = hit ? alpha_raw : 0.0f;
+        const float alc = __builtin_amdgcn_fmed3f(a_hit, a.cmax, -1.0f);  // min(alpha, cmax), one v_med3_f32 (:169)
+        const float T = Tr[b];
+        const float w = alc * T;
         float dot = 0.0f;
 #pragma unroll
         for (int c = 0; c < FP; ++c) dot += feat[c] * gpix[b][c];
-        Wt[b] += w;
+        Tr[b] = T - w;
         R[b] -= w * dot;
         // dL/dalpha = sum_c (f_c T - rem_c / (1 - alpha)) g_c   (:180-182)
-        const float alpha_grad = hit ? (T * dot - R[b] * gs_rcp_fast(1.0f - alc)) : 0.0f;
+        float alpha_grad = T * dot - R[b] * gs_rcp_fast(1.0f - alc);
+        if (FULL || HEUR) alpha_grad = hit ? alpha_grad : 0.0f;  // these also use it without the a_hit factor
 #pragma unroll
         for (int c = 0; c < FP; ++c) gf[c] += w * gpix[b][c];  // :201
         if (FULL) {
@@ -264,8 +269,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           S[7] += aag * aag;                                  // :194-198
           S[8] += fabsf(aag * dmx) + fabsf(aag * dmy);
         } else {
-          // moments in the ellipse frame (tx, ty are O(1): no cancellation for elongated splats)
-          const float G = p * alpha_grad;
+          // moments in the (scaled) ellipse frame (tx, ty are O(1): no cancellation for elongated splats), carrying
+          // the splat's opacity: G = alpha_p * pdf * dL/dalpha
+          const float G = a_hit * alpha_grad;
           const float Gtx = G * tx, Gty = G * ty;
           S[0] += G;
           S[1] += Gtx; S[2] += Gty;
@@ -273,7 +279,8 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           if (HEUR) {
             // backward.py:194-198 from the lean record: dp/dmean = p (tx A + ty B), A = axis / sx, B = perp(axis) / sy
             const float aag = g1v.z * alpha_grad;
-            const float dmx = p * (tx * g0v.z + ty * g1v.x), dmy = p * (tx * g0v.w + ty * g1v.y);
+            // the staged frame and tx, ty both carry K_EXP: dp/dmean = p (tx A + ty B) / K_EXP^2
+            const float dmx = p * IK2 * (tx * g0v.z + ty * g1v.x), dmy = p * IK2 * (tx * g0v.w + ty * g1v.y);
             S[6] += aag * aag;
             S[7] += fabsf(aag * dmx) + fabsf(aag * dmy);
           }
@@ -281,7 +288,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       }
 
       // reduce over the wave only if some pixel took a gradient (backward.py:204)
-      if (__ballot(has_grad) != 0ull) {
+      if (any_grad) {
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
         // up owning value k stores it (one ds_write_b32 for all values of a chunk)
         if (NACC <= 16) {
@@ -326,17 +333,20 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           // With d = (sx tx axis + sy ty perp(axis)) / |axis|^2 the position-weighted sums follow:
           //   sum G tx d = (sx Mxx axis + sy Mxy perp) / n2 ,  sum G ty d = (sx Mxy axis + sy Myy perp) / n2
           // and dp/dmean, dp/daxis, dp/dsigma (taichi_lib/generic.py:321-336) become
+          // the totals carry alpha_p (G = alpha_p pdf dL/dalpha) and powers of K_EXP (scaled tx, ty): undo both here
+          t[1] *= IK; t[2] *= IK;
+          t[3] *= IK2; t[4] *= IK2; t[5] *= IK2;
           const float sx = 1.0f / isx, sy = 1.0f / isy;
           const float in2 = 1.0f / (ax * ax + ay * ay);
           const float txdx = (sx * ax * t[3] - sy * ay * t[4]) * in2, txdy = (sx * ay * t[3] + sy * ax * t[4]) * in2;
           const float tydx = (sx * ax * t[4] - sy * ay * t[5]) * in2, tydy = (sx * ay * t[4] + sy * ax * t[5]) * in2;
-          row[0] = al * (t[1] * isx * ax - t[2] * isy * ay);
-          row[1] = al * (t[1] * isx * ay + t[2] * isy * ax);
-          row[2] = -al * (isx * txdx + isy * tydy);
-          row[3] = al * (isy * tydx - isx * txdy);
-          row[4] = al * t[3] * isx;
-          row[5] = al * t[5] * isy;
-          row[6] = t[0];
+          row[0] = t[1] * isx * ax - t[2] * isy * ay;
+          row[1] = t[1] * isx * ay + t[2] * isy * ax;
+          row[2] = -(isx * txdx + isy * tydy);
+          row[3] = isy * tydx - isx * txdy;
+          row[4] = t[3] * isx;
+          row[5] = t[5] * isy;
+          row[6] = t[0] / al;
           if (HEUR) { row[7 + FP] = t[6]; row[8 + FP] = t[7]; }
         }
 #pragma unroll

@@ -44,7 +44,7 @@ struct FwdArgs {
   int heavy_cap;
   const int* tile_order;  // optional launch order of the items (heaviest first)  // tiles * sub * sub
   float cmax, thr, sat_level;
-  float keep;  // a region is walked while some pixel's accumulated weight is below this (1 - forward_cut)
+  float cut;  // a region is walked while some pixel's transmittance is above this (GsRasterConfig.forward_cut)
   int blend, vis, aa;
   GsShard sh;  // owned tile rows: tile ids are local, H is the full image height, the image holds the owned rows
 };
@@ -73,7 +73,8 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
   constexpr bool FULL = MODE == 2, VIS = MODE >= 1;
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
-  float Xf[NB], Yf[NB], Wt[NB], acc[NB][FP];
+  // Tr = 1 - (accumulated weight W of forward.py:84-128): the transmittance in front of the next splat
+  float Xf[NB], Yf[NB], Tr[NB], acc[NB][FP];
   bool inb[NB], done[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -81,13 +82,16 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
     inb[b] = X < a.W && Y < a.H;
     Xf[b] = float(X) + 0.5f;
     Yf[b] = float(Y) + 0.5f;
-    Wt[b] = inb[b] ? 0.0f : 1.0f;  // forward.py:53-54
+    Tr[b] = inb[b] ? 1.0f : 0.0f;  // forward.py:53-54: out-of-image pixels start with W = 1
     done[b] = false;
 #pragma unroll
     for (int c = 0; c < FP; ++c) acc[b][c] = 0.0f;
   }
 
-  const int2 range = a.ranges[tile];
+  const int2 range_v = a.ranges[tile];
+  int2 range;  // wave-uniform: loop bounds in scalar registers
+  range.x = __builtin_amdgcn_readfirstlane(range_v.x);
+  range.y = __builtin_amdgcn_readfirstlane(range_v.y);
   const float k_exp = 0.84932180028801904f;  // sqrt(0.5 * log2(e)): exp(-0.5 t^2) = exp2(-(k t)^2)
 
   for (int g0 = range.x; g0 < range.y; g0 += 64) {
@@ -101,10 +105,10 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       live = 0;
 #pragma unroll
       for (int b = 0; b < NB; ++b)
-        if (__ballot(Wt[b] < a.keep) != 0ull) live |= 1 << b;
+        if (__ballot(Tr[b] > a.cut) != 0ull) live |= 1 << b;
       if (live == 0) break;
     }
-    const int cnt = min(64, range.y - g0);
+    const int cnt = __builtin_amdgcn_readfirstlane(min(64, range.y - g0));
     // ---- stage up to 64 splats: lane j <- splat g0 + j
     if (lane < cnt) {
       const int idx = a.o2p[g0 + lane];
@@ -119,19 +123,8 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       if (!use_mask) {
         mask = (1 << NB) - 1;
       } else if (al > a.thr) {
-        // two separating-axis pairs: the ellipse's axes (sub-block projected into the ellipse frame) and
-        // the image axes (the ellipse's bounding box against the sub-block)
-        const float r = sqrtf(__log2f(al / a.thr)) * 1.001f + 0.01f;
-        const float et = 3.5f * (fabsf(Ax) + fabsf(Ay)) + r, eb = 3.5f * (fabsf(Bx) + fabsf(By)) + r;
-        const float rp = r * (1.0f / k_exp);  // the same radius in units of sigma
-        const float ex = 3.5f + rp * sqrtf(ax * ax * sx * sx + ay * ay * sy * sy);
-        const float ey = 3.5f + rp * sqrtf(ay * ay * sx * sx + ax * ax * sy * sy);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          const float cx = float(x0 + (b & 1) * 8) + 4.0f - mx, cy = float(y0 + (b >> 1) * 8) + 4.0f - my;
-          const float tc = cx * Ax + cy * Ay, bc = cx * Bx + cy * By;
-          if (fabsf(tc) <= et && fabsf(bc) <= eb && fabsf(cx) <= ex && fabsf(cy) <= ey) mask |= 1 << b;
-        }
+        mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, __log2f(al / a.thr), float(x0) + 0.5f - mx,
+                                     float(y0) + 0.5f - my);
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
       s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
@@ -186,13 +179,13 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         const float al = __builtin_amdgcn_fmed3f(g1v.z * p, a.cmax, -1.0f);  // min(alpha, cmax) (forward.py:98-99)
         bool hit = al > a.thr;
         if (FULL) hit = hit && !done[b];
-        const float w = hit ? al * (1.0f - Wt[b]) : 0.0f;
-        Wt[b] += w;
+        const float w = (hit ? al : 0.0f) * Tr[b];
+        Tr[b] -= w;
         if (!FULL || a.blend) {
 #pragma unroll
           for (int c = 0; c < FP; ++c) acc[b][c] += feat[c] * w;
         } else if (hit) {  // forward.py:109-114 quantile mode: first splat that reaches the level
-          if (Wt[b] >= a.sat_level) {
+          if (1.0f - Tr[b] >= a.sat_level) {
 #pragma unroll
             for (int c = 0; c < FP; ++c) acc[b][c] = feat[c];
             done[b] = true;
@@ -224,7 +217,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 #pragma unroll
     for (int c = 0; c < FP; ++c)
       if (c < a.F) out[c] = acc[b][c];
-    a.alpha[pix] = (!FULL || a.blend) ? Wt[b] : (Wt[b] > 0.0f ? 1.0f : 0.0f);  // forward.py:134-137
+    a.alpha[pix] = (!FULL || a.blend) ? 1.0f - Tr[b] : (Tr[b] < 1.0f ? 1.0f : 0.0f);  // forward.py:134-137
   }
 }
 
@@ -318,8 +311,9 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   if (cfg->tune_no_heavy_split) a.heavy = nullptr;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
-  // Wt < keep  <=>  transmittance 1 - Wt above the cut (cut <= 0: walk while Wt < 1, i.e. while anything can change)
-  a.keep = cfg->forward_cut > 0.0f ? 1.0f - cfg->forward_cut : 1.0f;
+  // below 2^-25 (half an ulp of 1) the reference's own f32 accumulation W += w no longer changes W: walking further
+  // would add what the reference drops, so that is where forward_cut = 0 ("the reference literally") stops
+  a.cut = cfg->forward_cut > 2.98023223876953125e-08f ? cfg->forward_cut : 2.98023223876953125e-08f;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int mode = (!a.blend || a.aa) ? 2 : a.vis ? 1 : 0;

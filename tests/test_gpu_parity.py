@@ -144,8 +144,9 @@ def test_raster_forward_backward(seed, n, size, tile, F):
     # the backward consumes the forward's own image: give the oracle the HIP image so that the only
     # difference measured is the backward kernel
     gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
-    pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d")
-    pu.assert_grad_close(f_t.grad, gf, "grad_features")
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p, ranges, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
 
 
 @pytest.mark.parametrize("nb", [1, 2, 4])
@@ -170,8 +171,9 @@ def test_raster_wave_region_variants(nb, seed, n, size, tile, F, monkeypatch):
     gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(seed))
     (out.image * dev(gi)).sum().backward()
     gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
-    pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d")
-    pu.assert_grad_close(f_t.grad, gf, "grad_features")
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p, ranges, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
 
 
 @pytest.mark.parametrize("seed", range(3))
