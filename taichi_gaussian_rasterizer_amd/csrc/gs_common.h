@@ -234,6 +234,9 @@ __device__ __forceinline__ float gs_wave_reduce_transposed(float (&v)[N], int la
   return d;
 }
 
+__device__ __forceinline__ float gs_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+__device__ __forceinline__ float gs_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
+
 // Which of a wave region's NB 8x8 pixel sub-blocks can a splat reach?  (Ax, Ay), (Bx, By) are the rows of the map
 // d = pixel - mean  ->  t  in which alpha > alpha_threshold  <=>  |t|^2 < r2; (relx, rely) = first pixel centre of the
 // region minus the mean.  Per sub-block the EXACT minimum of the quadratic |t(d)|^2 over the block's 8x8 pixel centres
@@ -245,7 +248,8 @@ template <int NB>
 __device__ __forceinline__ int gs_sub_block_mask(float Ax, float Ay, float Bx, float By, float r2, float relx,
                                                  float rely) {
   const float sxx = Ax * Ax + Bx * Bx, sxy = Ax * Ay + Bx * By, syy = Ay * Ay + By * By;
-  const float rxy = -sxy / syy, ryx = -sxy / sxx;  // vertex of the parabola along an edge x = const / y = const
+  // vertex of the parabola along an edge x = const / y = const (v_rcp_f32: the slack below covers its 1 ulp)
+  const float rxy = -sxy * gs_rcp_fast(syy), ryx = -sxy * gs_rcp_fast(sxx);
   const float lim = r2 * 1.002f + 1e-3f;
   int mask = 0;
 #pragma unroll
@@ -261,8 +265,5 @@ __device__ __forceinline__ int gs_sub_block_mask(float Ax, float Ay, float Bx, f
   }
   return mask;
 }
-
-__device__ __forceinline__ float gs_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
-__device__ __forceinline__ float gs_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
 
 #endif  // __HIPCC__

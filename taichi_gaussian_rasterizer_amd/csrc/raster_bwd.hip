@@ -44,7 +44,7 @@ struct BwdArgs {
   const int* heavy;  // optional (device): the first *heavy entries of tile_order get four 8x8 workgroups each
   int heavy_cap;
   const int* tile_order;  // optional launch order of the items (heaviest first)
-  float cmax, thr, sat;
+  float cmax, thr, inv_thr, sat;
   int aa, heur;
   GsShard sh;  // owned tile rows: tile ids are local, H is the full image height, the images hold the owned rows
 };
@@ -160,7 +160,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       const float* p = a.points + int64_t(idx) * 7;
       const float mx = p[0], my = p[1];
       ax = p[2]; ay = p[3];
-      isx = 1.0f / p[4]; isy = 1.0f / p[5];
+      isx = gs_rcp_fast(p[4]); isy = gs_rcp_fast(p[5]);  // v_rcp_f32: 1 ulp, far inside the parity tolerance
       al = p[6];
       const float ks = FULL ? 1.0f : K_EXP;
       const float Ax = ax * isx * ks, Ay = ay * isx * ks, Bx = -ay * isy * ks, By = ax * isy * ks;
@@ -169,7 +169,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         mask = (1 << NB) - 1;
       } else if (al > a.thr) {
         // alpha * pdf > thr  needs  tx^2 + ty^2 < log2(alpha / thr)  (scaled frame; 2 ln(alpha / thr) unscaled)
-        const float r2 = __log2f(al / a.thr) * (FULL ? 1.38629436111989f : 1.0f);
+        const float r2 = __log2f(al * a.inv_thr) * (FULL ? 1.38629436111989f : 1.0f);
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, r2, float(x0) + 0.5f - mx, float(y0) + 0.5f - my);
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
@@ -254,9 +254,10 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 #pragma unroll
         for (int c = 0; c < FP; ++c) dot += feat[c] * gpix[b][c];
         Tr[b] = T - w;
+        // dL/dalpha = sum_c (f_c T - rem_c / (1 - alpha)) g_c   (:180-182) with rem = R - w dot, w = alpha T:
+        //           = (T dot - R) / (1 - alpha), R still including this splat's share
+        float alpha_grad = (T * dot - R[b]) * gs_rcp_fast(1.0f - alc);
         R[b] -= w * dot;
-        // dL/dalpha = sum_c (f_c T - rem_c / (1 - alpha)) g_c   (:180-182)
-        float alpha_grad = T * dot - R[b] * gs_rcp_fast(1.0f - alc);
         if (FULL || HEUR) alpha_grad = hit ? alpha_grad : 0.0f;  // these also use it without the a_hit factor
 #pragma unroll
         for (int c = 0; c < FP; ++c) gf[c] += w * gpix[b][c];  // :201
@@ -336,8 +337,8 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           // the totals carry alpha_p (G = alpha_p pdf dL/dalpha) and powers of K_EXP (scaled tx, ty): undo both here
           t[1] *= IK; t[2] *= IK;
           t[3] *= IK2; t[4] *= IK2; t[5] *= IK2;
-          const float sx = 1.0f / isx, sy = 1.0f / isy;
-          const float in2 = 1.0f / (ax * ax + ay * ay);
+          const float sx = gs_rcp_fast(isx), sy = gs_rcp_fast(isy);
+          const float in2 = gs_rcp_fast(ax * ax + ay * ay);
           const float txdx = (sx * ax * t[3] - sy * ay * t[4]) * in2, txdy = (sx * ay * t[3] + sy * ax * t[4]) * in2;
           const float tydx = (sx * ax * t[4] - sy * ay * t[5]) * in2, tydy = (sx * ay * t[4] + sy * ax * t[5]) * in2;
           row[0] = t[1] * isx * ax - t[2] * isy * ay;
@@ -346,7 +347,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           row[3] = isy * tydx - isx * txdy;
           row[4] = t[3] * isx;
           row[5] = t[5] * isy;
-          row[6] = t[0] / al;
+          row[6] = t[0] * gs_rcp_fast(al);
           if (HEUR) { row[7 + FP] = t[6]; row[8 + FP] = t[7]; }
         }
 #pragma unroll
@@ -470,6 +471,7 @@ extern "C" int gs_raster_bwd(int64_t v, int32_t num_features, const float* point
   a.heavy_cap = num_tiles / 4;
   if (cfg->tune_no_heavy_split) a.heavy = nullptr;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.sat = cfg->saturate_threshold;
+  a.inv_thr = 1.0f / cfg->alpha_threshold;
   a.aa = cfg->antialias; a.heur = cfg->compute_point_heuristic;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int mode = a.aa ? 2 : a.heur ? 1 : 0;

@@ -43,7 +43,7 @@ struct FwdArgs {
   const int* heavy;  // optional (device): the first *heavy entries of tile_order get four 8x8 workgroups each
   int heavy_cap;
   const int* tile_order;  // optional launch order of the items (heaviest first)  // tiles * sub * sub
-  float cmax, thr, sat_level;
+  float cmax, thr, inv_thr, sat_level;
   float cut;  // a region is walked while some pixel's transmittance is above this (GsRasterConfig.forward_cut)
   int blend, vis, aa;
   GsShard sh;  // owned tile rows: tile ids are local, H is the full image height, the image holds the owned rows
@@ -114,7 +114,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       const int idx = a.o2p[g0 + lane];
       const float* p = a.points + int64_t(idx) * 7;
       const float mx = p[0], my = p[1], ax = p[2], ay = p[3], sx = p[4], sy = p[5], al = p[6];
-      const float isx = 1.0f / sx, isy = 1.0f / sy;
+      const float isx = gs_rcp_fast(sx), isy = gs_rcp_fast(sy);  // v_rcp_f32: 1 ulp
       const float Ax = ax * isx * k_exp, Ay = ay * isx * k_exp;
       const float Bx = -ay * isy * k_exp, By = ax * isy * k_exp;
       // conservative sub-block mask: alpha*exp2(-(tx^2+ty^2)) > thr needs tx^2+ty^2 < log2(alpha/thr)
@@ -123,7 +123,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       if (!use_mask) {
         mask = (1 << NB) - 1;
       } else if (al > a.thr) {
-        mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, __log2f(al / a.thr), float(x0) + 0.5f - mx,
+        mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, __log2f(al * a.inv_thr), float(x0) + 0.5f - mx,
                                      float(y0) + 0.5f - my);
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
@@ -309,7 +309,7 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   a.heavy = (tile_order && ts == 16 && nb > 1) ? heavy_tiles : nullptr;
   a.heavy_cap = num_tiles / 4;
   if (cfg->tune_no_heavy_split) a.heavy = nullptr;
-  a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold;
+  a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.inv_thr = 1.0f / cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
   // below 2^-25 (half an ulp of 1) the reference's own f32 accumulation W += w no longer changes W: walking further
   // would add what the reference drops, so that is where forward_cut = 0 ("the reference literally") stops
