@@ -282,7 +282,8 @@ def main():
                 try:
                     rec = json.load(open(pmc)).get(args.workload, {}).get(dom)
                     if rec and world == 1:
-                        roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                        roofline["traffic"] = rec["hbm_bytes_per_launch"]  # FETCH_SIZE x2 (gfx950) + WRITE_SIZE
+                        roofline["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / per_launch, 3)
                         if "valu_wave_insts_per_launch" in rec:
                             # the kernel is f32-VALU-issue-bound (no MFMA shape, HBM far from saturated): second
                             # roofline = measured wave64 VALU instructions against the chip's issue rate
@@ -292,7 +293,9 @@ def main():
                                                     issue_frac=round(floor_ms / stages[dom]["avg_launch_ms"], 4))
                 except Exception:
                     pass
-    whole = sum(v for k, v in by.items() if wl["backward"] or not k.endswith(("_bwd", "_unpack")))
+    # only the entry points this frame actually ran (the fused frame consumes the gradient rows in place: no unpack)
+    ran = set(stages) or {k for k in by if wl["backward"] or not k.endswith(("_bwd", "_unpack"))}
+    whole = sum(v for k, v in by.items() if k in ran)
     sv = survey_bytes(wl["n"], V, K, T, W * H, F, 3, D, wl["backward"])
 
     cpu_baseline = None

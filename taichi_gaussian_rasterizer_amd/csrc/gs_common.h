@@ -266,4 +266,31 @@ __device__ __forceinline__ int gs_sub_block_mask(float Ax, float Ay, float Bx, f
   return mask;
 }
 
+// The same question for the antialiased pdf (taichi_lib/generic.py:341-357), whose support is a BOX in the splat's
+// frame, not an ellipse: pdf = tau sx sy D(ux; sx) D(uy; sy) with D(x; s) = S((x + 0.5) / s) - S((x - 0.5) / s),
+// S(z) = sigmoid(1.6 z + 0.07 z^3).  For |x| > 0.5:  D(x; s) <= 1 - S((|x| - 0.5) / s) <= exp(-g(z)), g(z) = 1.6 z + 0.07 z^3,
+// z = (|x| - 0.5) / s; so alpha = alpha_p pdf > thr needs g(z_x) < L_x = ln(alpha_p tau sx sy D(0; sy) / thr) (and the
+// same with x, y exchanged), and g(z) < L implies z < min(L / 1.6, cbrt(L / 0.07)).  Half extents X, Y of the box along
+// the axis (ax, ay) and its perpendicular; separating-axis test of that oriented box against each 8x8 block of pixel
+// centres (half extent 3.5).  d0x = D(0; sx), d0y = D(0; sy).  Returns 0 when the splat cannot reach the threshold.
+template <int NB>
+__device__ __forceinline__ int gs_sub_block_mask_antialias(float ax, float ay, float sx, float sy, float alpha,
+                                                           float inv_thr, float d0x, float d0y, float relx, float rely) {
+  const float base = alpha * 6.28318530717958648f * sx * sy * inv_thr;
+  const float Lx = __logf(base * d0y), Ly = __logf(base * d0x);
+  if (!(Lx > 0.0f && Ly > 0.0f)) return 0;
+  const float zx = fminf(Lx * 0.625f, cbrtf(Lx * 14.2857142857f)), zy = fminf(Ly * 0.625f, cbrtf(Ly * 14.2857142857f));
+  const float X = (0.5f + sx * zx) * 1.001f + 0.01f, Y = (0.5f + sy * zy) * 1.001f + 0.01f;
+  const float h = 3.5f * (fabsf(ax) + fabsf(ay));
+  const float ex = 3.5f + X * fabsf(ax) + Y * fabsf(ay), ey = 3.5f + X * fabsf(ay) + Y * fabsf(ax);
+  int mask = 0;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const float cx = relx + float((b & 1) * 8) + 3.5f, cy = rely + float((b >> 1) * 8) + 3.5f;  // block centre - mean
+    if (fabsf(cx * ax + cy * ay) <= X + h && fabsf(cy * ax - cx * ay) <= Y + h && fabsf(cx) <= ex && fabsf(cy) <= ey)
+      mask |= 1 << b;
+  }
+  return mask;
+}
+
 #endif  // __HIPCC__

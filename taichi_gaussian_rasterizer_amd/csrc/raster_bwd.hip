@@ -166,7 +166,12 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       const float Ax = ax * isx * ks, Ay = ay * isx * ks, Bx = -ay * isy * ks, By = ax * isy * ks;
       int mask = 0;
       if (FULL && a.aa) {
-        mask = (1 << NB) - 1;
+        float s1, s2, u0, u1;
+        s_sig_grad(0.5f, isx, s1, u0, u1);
+        s_sig_grad(0.5f, isy, s2, u0, u1);
+        // D(0; s) = S(0.5 / s) - S(-0.5 / s) = 2 S(0.5 / s) - 1
+        mask = gs_sub_block_mask_antialias<NB>(ax, ay, p[4], p[5], al, a.inv_thr, 2.0f * s1 - 1.0f, 2.0f * s2 - 1.0f,
+                                               float(x0) + 0.5f - mx, float(y0) + 0.5f - my);
       } else if (al > a.thr) {
         // alpha * pdf > thr  needs  tx^2 + ty^2 < log2(alpha / thr)  (scaled frame; 2 ln(alpha / thr) unscaled)
         const float r2 = __log2f(al * a.inv_thr) * (FULL ? 1.38629436111989f : 1.0f);

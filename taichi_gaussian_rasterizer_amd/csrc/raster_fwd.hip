@@ -64,13 +64,15 @@ __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
 }
 
 // NB: 8x8 sub-blocks per wave (1, 2 or 4; gs_raster_sub_blocks picks it from the grid size).  FP: padded feature width.
+// MODE 3: lean quantile pass (no blending, no antialias, no statistics: the median-depth pass of renderer.py:203-208);
 // MODE 0: blend only (lean); 1: blend + per-splat visibility (training with pruning statistics);
 // 2: runtime switches for quantile mode / antialias (+ visibility).
 template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0, int yout0,
                                                 float4 (*s_geo)[MODE == 2 ? 3 : 2], float (*s_feat)[FP], float* s_vis,
                                                 int* s_idx) {
-  constexpr bool FULL = MODE == 2, VIS = MODE >= 1;
+  constexpr bool FULL = MODE == 2, VIS = MODE == 1 || MODE == 2, QUANT = MODE == 3;
+  const bool blend = QUANT ? false : (FULL ? a.blend != 0 : true);
   const int lane = threadIdx.x;
   const int lx = lane & 7, ly = lane >> 3;
   // Tr = 1 - (accumulated weight W of forward.py:84-128): the transmittance in front of the next splat
@@ -100,14 +102,19 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
     // forward_cut * max|feature| in total, so the rest of a crowded tile's list is skipped (forward_cut = 0: only
     // where the f32 transmittance is exactly zero, i.e. every further weight is 0.0f -- the reference literally).
     // The same holds per 8x8 sub-block: a saturated one is masked out for the rest of the list.
-    int live = (1 << NB) - 1;
-    if (!FULL || a.blend) {
-      live = 0;
+    int live = 0;
+    if (blend) {
 #pragma unroll
       for (int b = 0; b < NB; ++b)
         if (__ballot(Tr[b] > a.cut) != 0ull) live |= 1 << b;
-      if (live == 0) break;
+    } else {
+      // quantile mode (forward.py:109-114): a pixel is finished once a splat has taken it to the level; the walk ends
+      // with the region's last unfinished pixel (the median-depth pass stops after the front of each list)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+        if (__ballot(inb[b] && !done[b]) != 0ull) live |= 1 << b;
     }
+    if (live == 0) break;
     const int cnt = __builtin_amdgcn_readfirstlane(min(64, range.y - g0));
     // ---- stage up to 64 splats: lane j <- splat g0 + j
     if (lane < cnt) {
@@ -119,9 +126,10 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       const float Bx = -ay * isy * k_exp, By = ax * isy * k_exp;
       // conservative sub-block mask: alpha*exp2(-(tx^2+ty^2)) > thr needs tx^2+ty^2 < log2(alpha/thr)
       int mask = 0;
-      const bool use_mask = !(FULL && a.aa);
-      if (!use_mask) {
-        mask = (1 << NB) - 1;
+      if (FULL && a.aa) {
+        mask = gs_sub_block_mask_antialias<NB>(ax, ay, sx, sy, al, a.inv_thr, s_sig(0.5f, isx) - s_sig(-0.5f, isx),
+                                               s_sig(0.5f, isy) - s_sig(-0.5f, isy), float(x0) + 0.5f - mx,
+                                               float(y0) + 0.5f - my);
       } else if (al > a.thr) {
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, __log2f(al * a.inv_thr), float(x0) + 0.5f - mx,
                                      float(y0) + 0.5f - my);
@@ -178,10 +186,10 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         }
         const float al = __builtin_amdgcn_fmed3f(g1v.z * p, a.cmax, -1.0f);  // min(alpha, cmax) (forward.py:98-99)
         bool hit = al > a.thr;
-        if (FULL) hit = hit && !done[b];
+        if (FULL || QUANT) hit = hit && !done[b];
         const float w = (hit ? al : 0.0f) * Tr[b];
         Tr[b] -= w;
-        if (!FULL || a.blend) {
+        if (blend) {
 #pragma unroll
           for (int c = 0; c < FP; ++c) acc[b][c] += feat[c] * w;
         } else if (hit) {  // forward.py:109-114 quantile mode: first splat that reaches the level
@@ -217,7 +225,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 #pragma unroll
     for (int c = 0; c < FP; ++c)
       if (c < a.F) out[c] = acc[b][c];
-    a.alpha[pix] = (!FULL || a.blend) ? 1.0f - Tr[b] : (Tr[b] < 1.0f ? 1.0f : 0.0f);  // forward.py:134-137
+    a.alpha[pix] = blend ? 1.0f - Tr[b] : (Tr[b] < 1.0f ? 1.0f : 0.0f);  // forward.py:134-137
   }
 }
 
@@ -229,8 +237,8 @@ template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
   __shared__ float4 s_geo[64][MODE == 2 ? 3 : 2];
   __shared__ float s_feat[64][FP];
-  __shared__ float s_vis[MODE >= 1 ? 64 : 1];
-  __shared__ int s_idx[MODE >= 1 ? 64 : 1];
+  __shared__ float s_vis[(MODE == 1 || MODE == 2) ? 64 : 1];
+  __shared__ int s_idx[(MODE == 1 || MODE == 2) ? 64 : 1];
   const int per_tile = a.sub_x * a.sub_y;
   constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
   int tile, quad;
@@ -265,7 +273,8 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
 template <int NB, int MODE>
 int launch_fp(const FwdArgs& a, hipStream_t s) {
   const int grid = 8 * int(gs_div_up(a.num_items + (a.heavy ? 4 * a.heavy_cap : 0), 8));
-  if (a.F <= 3) hipLaunchKernelGGL((raster_fwd_kernel<NB, 3, MODE>), dim3(grid), dim3(64), 0, s, a);
+  if (MODE == 3 && a.F == 1) hipLaunchKernelGGL((raster_fwd_kernel<NB, 1, MODE>), dim3(grid), dim3(64), 0, s, a);
+  else if (a.F <= 3) hipLaunchKernelGGL((raster_fwd_kernel<NB, 3, MODE>), dim3(grid), dim3(64), 0, s, a);
   else if (a.F <= 5) hipLaunchKernelGGL((raster_fwd_kernel<NB, 5, MODE>), dim3(grid), dim3(64), 0, s, a);
   else if (a.F <= 8) hipLaunchKernelGGL((raster_fwd_kernel<NB, 8, MODE>), dim3(grid), dim3(64), 0, s, a);
   else hipLaunchKernelGGL((raster_fwd_kernel<NB, 32, MODE>), dim3(grid), dim3(64), 0, s, a);
@@ -316,8 +325,13 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   a.cut = cfg->forward_cut > 2.98023223876953125e-08f ? cfg->forward_cut : 2.98023223876953125e-08f;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int mode = (!a.blend || a.aa) ? 2 : a.vis ? 1 : 0;
-  if (nb == 1) return mode == 2 ? launch_fp<1, 2>(a, s) : mode == 1 ? launch_fp<1, 1>(a, s) : launch_fp<1, 0>(a, s);
-  if (nb == 2) return mode == 2 ? launch_fp<2, 2>(a, s) : mode == 1 ? launch_fp<2, 1>(a, s) : launch_fp<2, 0>(a, s);
-  return mode == 2 ? launch_fp<4, 2>(a, s) : mode == 1 ? launch_fp<4, 1>(a, s) : launch_fp<4, 0>(a, s);
+  const int mode = (!a.blend && !a.aa && !a.vis) ? 3 : (!a.blend || a.aa) ? 2 : a.vis ? 1 : 0;
+  if (nb == 1)
+    return mode == 3 ? launch_fp<1, 3>(a, s) : mode == 2 ? launch_fp<1, 2>(a, s) : mode == 1 ? launch_fp<1, 1>(a, s)
+                                                                                              : launch_fp<1, 0>(a, s);
+  if (nb == 2)
+    return mode == 3 ? launch_fp<2, 3>(a, s) : mode == 2 ? launch_fp<2, 2>(a, s) : mode == 1 ? launch_fp<2, 1>(a, s)
+                                                                                              : launch_fp<2, 0>(a, s);
+  return mode == 3 ? launch_fp<4, 3>(a, s) : mode == 2 ? launch_fp<4, 2>(a, s) : mode == 1 ? launch_fp<4, 1>(a, s)
+                                                                                            : launch_fp<4, 0>(a, s);
 }

@@ -111,25 +111,33 @@ def relative_eigen_gap(points):
     return np.sqrt((c00 - c11) ** 2 + 4 * c01 ** 2) / (c00 + c11)
 
 
-def assert_rows_close_e2e(hip, ref, relgap, name):
-    """relgap: per ROW of hip / ref (np.inf for rows without a projected splat)"""
-    hip, ref = to_np(hip).astype(np.float64), to_np(ref).astype(np.float64)
-    hip, ref = hip.reshape(hip.shape[0], -1), ref.reshape(ref.shape[0], -1)
+def assert_rows_close_e2e(hip, ref32, ref64, relgap, name):
+    """relgap: per ROW (np.inf for rows without a projected splat).  Both f32 pipelines -- the HIP one and the f32 oracle
+    -- are measured against the f64 oracle pipeline: the HIP path must keep at least E2E_FRAC of the well-conditioned
+    rows within E2E_TOL of the truth, or as many as the f32 oracle keeps (on deeply saturated pixels the oracle's
+    literal W-accumulation, T = 1 - W, is the less accurate of the two: see assert_grad_close_vs_truth)."""
+    hip, r32, r64 = (to_np(x).astype(np.float64).reshape(np.shape(to_np(x))[0], -1) for x in (hip, ref32, ref64))
     assert np.isfinite(hip).all(), f"{name}: non-finite values"
     visible = np.isfinite(relgap)
     keep = relgap >= GAP_EXCLUDE
     excluded = 1.0 - keep[visible].mean() if visible.any() else 0.0
     assert excluded <= MAX_GAP_EXCLUDED, f"{name}: {excluded:.4f} of the visible rows have an eigenvalue gap < {GAP_EXCLUDE}"
-    err = np.linalg.norm(hip - ref, axis=1)
-    mag = np.linalg.norm(ref, axis=1)
+    mag = np.linalg.norm(r64, axis=1)
     floor = 1e-3 * float(np.median(mag[mag > 0])) if (mag > 0).any() else 1e-20
-    rel = err / (mag + floor)
-    ok = rel[keep] <= E2E_TOL
-    med = float(np.median(rel[keep & visible])) if (keep & visible).any() else 0.0
-    assert ok.mean() >= E2E_FRAC, (f"{name}: only {ok.mean():.5f} of the well-conditioned rows within {E2E_TOL} "
-                                   f"(need {E2E_FRAC}; {excluded:.4f} excluded for their eigenvalue gap)")
-    assert med <= E2E_MEDIAN, f"{name}: median row error {med:.3e} > {E2E_MEDIAN}"
-    return dict(excluded_for_gap=float(excluded), within_tol=float(ok.mean()), median=med)
+
+    def score(x):
+        rel = np.linalg.norm(x - r64, axis=1) / (mag + floor)
+        med = float(np.median(rel[keep & visible])) if (keep & visible).any() else 0.0
+        return float((rel[keep] <= E2E_TOL).mean()), med
+
+    frac_hip, med_hip = score(hip)
+    frac_ref, med_ref = score(r32)
+    need = min(E2E_FRAC, frac_ref - 3e-3)  # 3e-3: a handful of rows on the 3 000-Gaussian cases (measured: -1.7e-3 .. +2e-3)
+    assert frac_hip >= need, (f"{name}: only {frac_hip:.5f} of the well-conditioned rows within {E2E_TOL} of the f64 result "
+                              f"(need {need:.5f}; the f32 oracle keeps {frac_ref:.5f}; {excluded:.4f} excluded for their "
+                              f"eigenvalue gap)")
+    assert med_hip <= max(E2E_MEDIAN, 2.0 * med_ref), f"{name}: median row error {med_hip:.3e} (f32 oracle: {med_ref:.3e})"
+    return dict(excluded_for_gap=float(excluded), within_tol=frac_hip, oracle_f32_within_tol=frac_ref, median=med_hip)
 
 
 def cov_form(points):
@@ -140,19 +148,22 @@ def cov_form(points):
                      ay * ay * sx * sx + ax * ax * sy * sy, p[:, 6]], 1)
 
 
-def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, use_depth16=False, grads=None):
-    """Full render_gaussians on the CPU oracle (f32).  gaussians: Gaussians3D on CPU.
+def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, use_depth16=False, grads=None,
+                  dtype=np.float32):
+    """Full render_gaussians on the CPU oracle (f32; dtype=np.float64 runs every floating-point stage in double --
+    the tile mapper stays f32, it has no other form in the reference either -- as the yardstick for comparisons
+    between two f32 pipelines).  gaussians: Gaussians3D on CPU.
     grads: dict with 'image' (and optionally 'depth', 'depth_var') upstream gradients -> also returns
     parameter gradients computed by chaining the oracle's backward stages."""
     cfg = orc.OracleConfig.of(config)
-    pos, ls, rot, al = (to_np(t).astype(np.float32) for t in gaussians.shape_tensors())
-    T = to_np(camera.T_camera_world).astype(np.float32)
-    proj = to_np(camera.projection).astype(np.float32)
+    pos, ls, rot, al = (to_np(t).astype(dtype) for t in gaussians.shape_tensors())
+    T = to_np(camera.T_camera_world).astype(dtype)
+    proj = to_np(camera.projection).astype(dtype)
     size = tuple(int(x) for x in camera.image_size)
     points, depth, idx = orc.project(pos, ls, rot, al, T, proj, size, camera.depth_range, blur_cov=cfg.blur_cov,
                                      clamp_margin=cfg.clamp_margin, alpha_threshold=cfg.alpha_threshold)
-    feat_in = to_np(gaussians.feature).astype(np.float32)
-    cam_pos = np.linalg.inv(T.astype(np.float64))[:3, 3].astype(np.float32)
+    feat_in = to_np(gaussians.feature).astype(dtype)
+    cam_pos = np.linalg.inv(T.astype(np.float64))[:3, 3].astype(dtype)
     if use_sh:
         feats = orc.evaluate_sh_at(feat_in, pos, idx, cam_pos)
     else:
@@ -160,7 +171,7 @@ def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, u
     ndc = orc.ndc_depth(depth, camera.near_plane, camera.far_plane)
     C = feats.shape[1]
     if render_depth:
-        feats_r = np.concatenate([depth, depth ** 2, feats], 1).astype(np.float32)
+        feats_r = np.concatenate([depth, depth ** 2, feats], 1).astype(dtype)
     else:
         feats_r = feats
     o2p, ranges = orc.map_to_tiles(points, ndc, size, cfg, use_depth16)
@@ -168,7 +179,7 @@ def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, u
     out = dict(points=points, depth=depth, indexes=idx, features=feats, o2p=o2p, ranges=ranges, alpha=alpha,
                visibility=vis, ndc=ndc)
     if render_depth:
-        w = alpha + np.float32(1e-6)
+        w = alpha + dtype(1e-6)
         d = image[..., 0] / w
         out.update(image=image[..., 2:], depth_img=d, depth_var=image[..., 1] / w - d ** 2)
     else:
@@ -179,9 +190,9 @@ def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, u
     g_img = np.zeros_like(image)
     if render_depth:
         g_img[..., 2:] = grads["image"]
-        w = alpha + np.float32(1e-6)
-        gd = grads.get("depth", np.zeros_like(alpha)).astype(np.float32)
-        gv = grads.get("depth_var", np.zeros_like(alpha)).astype(np.float32)
+        w = alpha + dtype(1e-6)
+        gd = grads.get("depth", np.zeros_like(alpha)).astype(dtype)
+        gv = grads.get("depth_var", np.zeros_like(alpha)).astype(dtype)
         d = image[..., 0] / w
         # depth = I0/w ; var = I1/w - depth^2   (weight is non-differentiable)
         g_img[..., 0] = (gd - 2 * d * gv) / w
@@ -191,7 +202,7 @@ def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, u
     gg, gf, heur = orc.rasterize_backward(points, feats_r, o2p, ranges, size, image, g_img, cfg)
     g_depth = np.zeros_like(depth)
     if render_depth:
-        g_depth = (gf[:, 0:1] + 2 * depth * gf[:, 1:2]).astype(np.float32)
+        g_depth = (gf[:, 0:1] + 2 * depth * gf[:, 1:2]).astype(dtype)
         gf = gf[:, 2:]
     dpos, dls, drot, dal, dT, dproj = orc.project_backward(pos, ls, rot, al, T, proj, size, idx, gg, g_depth,
                                                            blur_cov=cfg.blur_cov, clamp_margin=cfg.clamp_margin)

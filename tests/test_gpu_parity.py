@@ -436,6 +436,8 @@ def test_render_gaussians_end_to_end_vs_oracle(seed, n, size, deg, depth_mode):
     cfg = RasterConfig()
     gi = torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(seed + 7))
     ref = pu.oracle_render(g, camera, cfg, use_sh=True, render_depth=depth_mode, grads=dict(image=gi.numpy()))
+    ref64 = pu.oracle_render(g, camera, cfg, use_sh=True, render_depth=depth_mode,
+                             grads=dict(image=gi.numpy().astype(np.float64)), dtype=np.float64)
     gd = g.to(DEV).requires_grad_(True)
     r = gs.render_gaussians(gd, camera.to(device=DEV), cfg, use_sh=True, render_depth=depth_mode)
     assert (pu.to_np(r.points_in_view) == ref["indexes"]).all()
@@ -446,7 +448,7 @@ def test_render_gaussians_end_to_end_vs_oracle(seed, n, size, deg, depth_mode):
     relgap[ref["indexes"]] = pu.relative_eigen_gap(ref["points"])
     for name, key in (("position", "d_position"), ("log_scaling", "d_log_scaling"), ("rotation", "d_rotation"),
                       ("alpha_logit", "d_alpha_logit"), ("feature", "d_feature")):
-        rep = pu.assert_rows_close_e2e(getattr(gd, name).grad, ref[key], relgap, f"grad {name}")
+        rep = pu.assert_rows_close_e2e(getattr(gd, name).grad, ref[key], ref64[key], relgap, f"grad {name}")
         print(f"e2e seed {seed} {name}: {rep}")
 
 

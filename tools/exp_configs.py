@@ -12,7 +12,8 @@ gg = g.to('cuda:0').requires_grad_(True)
 cases = [("default", RasterConfig(), {}), ("tile 8", RasterConfig(tile_size=8), {}), ("tile 32", RasterConfig(tile_size=32), {}),
          ("antialias", RasterConfig(antialias=True, blur_cov=0.0), {}),
          ("visibility+heuristics", RasterConfig(compute_visibility=True, compute_point_heuristic=True), {}),
-         ("depth16", RasterConfig(), dict(use_depth16=True)), ("render_depth", RasterConfig(), dict(render_depth=True))]
+         ("depth16", RasterConfig(), dict(use_depth16=True)), ("render_depth", RasterConfig(), dict(render_depth=True)),
+         ("median_depth", RasterConfig(), dict(render_median_depth=True))]
 for name, cfg, kw in cases:
     def step():
         for _, t in gg.items(): t.grad = None
@@ -23,5 +24,5 @@ for name, cfg, kw in cases:
     nv.timer.reset(); nv.timer.only = None; nv.timer.enabled = True
     for _ in range(8): step()
     torch.cuda.synchronize(); nv.timer.enabled = False
-    st = {k[3:]: round(v[1] / 8, 3) for k, v in nv.timer.summary().items()}
+    st = {k[3:]: round(v[1] / 8, 3) for k, v in nv.timer.summary().items()}  # raster_fwd of median_depth = both passes
     print(f"{name:22s} total {sum(st.values()):.3f} ms  {st}", flush=True)
