@@ -213,7 +213,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         float dmx = 0, dmy = 0, dax = 0, day = 0, dsx = 0, dsy = 0;
         if (FULL && a.aa) {
           // taichi_lib/generic.py:371-404
-          const float axv = g2v.x, ayv = g2v.y, sxv = 1.0f / g2v.z, syv = 1.0f / g2v.w;
+          const float axv = g2v.x, ayv = g2v.y, sxv = gs_rcp_fast(g2v.z), syv = gs_rcp_fast(g2v.w);
           const float ux = dx * axv + dy * ayv, uy = dy * axv - dx * ayv;
           float Sx1, dSx1, dSx1s, Sx2, dSx2, dSx2s, Sy1, dSy1, dSy1s, Sy2, dSy2, dSy2s;
           s_sig_grad(ux + 0.5f, g2v.z, Sx1, dSx1, dSx1s);

@@ -63,6 +63,19 @@ __device__ __forceinline__ float s_sig(float x, float inv_sigma) {
   return gs_rcp_fast(1.0f + gs_exp2_fast(e * 1.44269504088896341f));
 }
 
+// One axis of the antialiased pdf (taichi_lib/generic.py:341-357): D(t) = S((t + 0.5) / s) - S((t - 0.5) / s) with
+// S(z) = 1 / (1 + e(z)), e(z) = exp(-(1.6 z + 0.07 z^3)), returned as num / den = (e_b - e_a) / ((1 + e_a)(1 + e_b)) so
+// that both axes share ONE reciprocal.  D is even (S(-z) = 1 - S(z)), so |t| is used: a >= 0 keeps e_a <= 1, and b is
+// clamped at -5, where S(b) < 5e-8 (e_b stays below 2e7: no overflow in the product of the two axes).
+__device__ __forceinline__ void aa_axis(float t, float inv_sigma, float& num, float& den) {
+  const float u = fabsf(t);
+  const float za = (u + 0.5f) * inv_sigma, zb = fmaxf((u - 0.5f) * inv_sigma, -5.0f);
+  const float c1 = -1.6f * 1.44269504088896341f, c3 = -0.07f * 1.44269504088896341f;
+  const float ea = gs_exp2_fast(za * (c1 + c3 * za * za)), eb = gs_exp2_fast(zb * (c1 + c3 * zb * zb));
+  num = eb - ea;
+  den = (1.0f + ea) * (1.0f + eb);
+}
+
 // NB: 8x8 sub-blocks per wave (1, 2 or 4; gs_raster_sub_blocks picks it from the grid size).  FP: padded feature width.
 // MODE 3: lean quantile pass (no blending, no antialias, no statistics: the median-depth pass of renderer.py:203-208);
 // MODE 0: blend only (lean); 1: blend + per-splat visibility (training with pruning statistics);
@@ -177,9 +190,11 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         if (FULL && a.aa) {
           // taichi_lib/generic.py:347-357
           const float tx = dx * g2v.x + dy * g2v.y, ty = dy * g2v.x - dx * g2v.y;
-          const float sxv = 1.0f / g2v.z, syv = 1.0f / g2v.w;
-          p = 6.28318530717958648f * sxv * (s_sig(tx + 0.5f, g2v.z) - s_sig(tx - 0.5f, g2v.z)) * syv *
-              (s_sig(ty + 0.5f, g2v.w) - s_sig(ty - 0.5f, g2v.w));
+          float nx, dx_, ny, dy_;
+          aa_axis(tx, g2v.z, nx, dx_);
+          aa_axis(ty, g2v.w, ny, dy_);
+          // tau sx sy D(tx) D(ty); sx sy = 1 / (isx isy) goes into the same reciprocal
+          p = 6.28318530717958648f * nx * ny * gs_rcp_fast(dx_ * dy_ * g2v.z * g2v.w);
         } else {
           const float tx = dx * g0v.z + dy * g0v.w, ty = dx * g1v.x + dy * g1v.y;
           p = gs_exp2_fast(-(tx * tx + ty * ty));
