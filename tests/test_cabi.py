@@ -61,3 +61,24 @@ def test_argument_errors_are_reported_not_crashed():
     assert rc == -1 and b"NULL" in lib.gs_last_error()
     with pytest.raises(ValueError):
         _native.check(rc, "gs_radix_sort_pairs")
+
+
+def test_row_shard_argument_is_validated():
+    """GsRowShard (screen-tile sharding): rows outside the image, a bad interleave, a shard that owns no row -- all
+    refused on the host, before any launch; the struct layout seen through ctypes is the header's"""
+    lib = _native.lib()
+    cfg = _native.GsRasterConfig(tile_size=16, alpha_threshold=1 / 255., forward_cut=2.0 ** -20)
+    assert [f[0] for f in _native.GsRowShard._fields_] == ["row_begin", "row_end", "band", "period", "phase"]
+    assert ctypes.sizeof(_native.GsRowShard) == 20 and ctypes.sizeof(_native.GsRasterConfig) == 60
+
+    def prepare(shard):
+        return lib.gs_map_prepare(0, None, None, 64, 64, cfg, 0, None, None, None, ctypes.byref(shard), None, 0, None)
+
+    assert prepare(_native.GsRowShard(0, 9, 4, 1, 0)) == -1 and b"tile rows" in lib.gs_last_error()     # 64 px = 4 rows
+    assert prepare(_native.GsRowShard(1, 3, 1, 2, 0)) == -1 and b"interleaved" in lib.gs_last_error()   # must span all
+    assert prepare(_native.GsRowShard(0, 4, 1, 2, 2)) == -1 and b"phase" in lib.gs_last_error()
+    assert prepare(_native.GsRowShard(2, 2, 4, 1, 0)) == -1 and b"owns no tile row" in lib.gs_last_error()
+    # a valid shard gets past the shard checks (and stops at the NULL buffers)
+    assert prepare(_native.GsRowShard(1, 3, 4, 1, 0)) == -1 and b"NULL buffer" in lib.gs_last_error()
+    # an interleaved shard that deals every band to other owners: rows 0-3 in bands of 2 over 4 owners, owner 3
+    assert prepare(_native.GsRowShard(0, 4, 2, 4, 3)) == -1 and b"owns no tile row" in lib.gs_last_error()
