@@ -160,26 +160,25 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
     }
     __syncthreads();  // single-wave workgroup: compiles to a wait on the LDS writes, no s_barrier
 
-    // ---- blend.  The next splat's record is fetched from LDS while the current one is blended
-    // (one wave-uniform ds_read burst per splat, its latency hidden behind ~40-90 VALU instructions).
-    float4 n0 = s_geo[0][0], n1 = s_geo[0][1], n2 = make_float4(0, 0, 0, 0);
-    float nfeat[FP];
+    // ---- blend.  The next splat's record is fetched from LDS while the current one is blended (one wave-uniform
+    // ds_read burst per splat, its latency hidden behind ~40-90 VALU instructions).  Two register sets take turns
+    // (A is blended while B is in flight and vice versa): rotating ONE set cost 12 v_mov per splat, a fifth of the
+    // kernel's vector instructions.
+    struct Rec {
+      float4 g0, g1, g2;
+      float f[FP];
+    };
+    auto fetch = [&](int j, Rec& r) {
+      const int jj = j < cnt ? j : cnt - 1;
+      r.g0 = s_geo[jj][0];
+      r.g1 = s_geo[jj][1];
+      if (FULL) r.g2 = s_geo[jj][2];
 #pragma unroll
-    for (int c = 0; c < FP; ++c) nfeat[c] = s_feat[0][c];
-    if (FULL) n2 = s_geo[0][2];
-    for (int j = 0; j < cnt; ++j) {
-      const float4 g0v = n0, g1v = n1, g2v = n2;
-      float feat[FP];
-#pragma unroll
-      for (int c = 0; c < FP; ++c) feat[c] = nfeat[c];
-      {
-        const int jn = j + 1 < cnt ? j + 1 : j;
-        n0 = s_geo[jn][0];
-        n1 = s_geo[jn][1];
-        if (FULL) n2 = s_geo[jn][2];
-#pragma unroll
-        for (int c = 0; c < FP; ++c) nfeat[c] = s_feat[jn][c];
-      }
+      for (int c = 0; c < FP; ++c) r.f[c] = s_feat[jj][c];
+    };
+    auto blend_splat = [&](int j, const Rec& r) {
+      const float4 g0v = r.g0, g1v = r.g1, g2v = FULL ? r.g2 : make_float4(0, 0, 0, 0);
+      const float(&feat)[FP] = r.f;
       const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
       float vis_sum = 0.0f;
 #pragma unroll
@@ -223,6 +222,14 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
           if (lane == 63) s_vis[j] += tot;
         }
       }
+    };
+    Rec ra, rb;
+    fetch(0, ra);
+    for (int j = 0; j < cnt; j += 2) {
+      fetch(j + 1, rb);
+      blend_splat(j, ra);
+      fetch(j + 2, ra);
+      if (j + 1 < cnt) blend_splat(j + 1, rb);
     }
     if (VIS && a.vis) {
       __syncthreads();
