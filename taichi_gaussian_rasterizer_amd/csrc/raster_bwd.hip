@@ -253,16 +253,17 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         // for the weight, the feature gradients and the moments
         const float a_hit = hit ? alpha_raw : 0.0f;
         const float alc = __builtin_amdgcn_fmed3f(a_hit, a.cmax, -1.0f);  // min(alpha, cmax), one v_med3_f32 (:169)
-        const float T = Tr[b];
-        const float w = alc * T;
         float dot = 0.0f;
 #pragma unroll
         for (int c = 0; c < FP; ++c) dot += feat[c] * gpix[b][c];
-        Tr[b] = T - w;
         // dL/dalpha = sum_c (f_c T - rem_c / (1 - alpha)) g_c   (:180-182) with rem = R - w dot, w = alpha T:
-        //           = (T dot - R) / (1 - alpha), R still including this splat's share
-        float alpha_grad = (T * dot - R[b]) * gs_rcp_fast(1.0f - alc);
+        //           = (T dot - R) / (1 - alpha), R still including this splat's share.  The numerator is formed before
+        // T and R are updated so that both updates happen in place (no register copies at the end of the block).
+        const float num = Tr[b] * dot - R[b];
+        const float w = alc * Tr[b];
+        Tr[b] -= w;
         R[b] -= w * dot;
+        float alpha_grad = num * gs_rcp_fast(1.0f - alc);
         if (FULL || HEUR) alpha_grad = hit ? alpha_grad : 0.0f;  // these also use it without the a_hit factor
 #pragma unroll
         for (int c = 0; c < FP; ++c) gf[c] += w * gpix[b][c];  // :201
