@@ -501,7 +501,11 @@ def test_sharded_strips_on_one_gpu(world):
         rr = parallel.render_gaussians_sharded(g.to(DEV), cam, cfg, use_sh=True, rank=rank, world_size=world,
                                                ops=parallel.default_ops())
         strips2.append(rr.image.detach())
-    assert torch.equal(torch.cat(strips2, 0), r.image.detach())
+    # band by band on shifted means: a marginal tile decision can differ from the full frame's (the mapper rounds
+    # loy = my - ey once more), which moves the 64-splat group boundaries at which the forward may stop a saturated
+    # region -- below forward_cut * |feature| = 1e-6 per pixel, but no longer bit for bit (the kernel-level shards
+    # above are: they work in full-image coordinates)
+    assert torch.allclose(torch.cat(strips2, 0), r.image.detach(), rtol=0, atol=2e-6)
 
 
 # ------------------------------------------- full-size properties (BASELINE config 3 shapes)
