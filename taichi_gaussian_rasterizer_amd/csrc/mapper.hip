@@ -773,7 +773,11 @@ __device__ __forceinline__ void rank_sort_rows(uint64_t* s_key, int n, int lane,
 // own population, so a 100-splat tile in a frame whose fullest tile holds 500 does 2 rows of
 // compares, not 8.
 template <int RMAX>
-__global__ __launch_bounds__(64) void tile_rank_sort_kernel(int num_tiles, const int2* tile_ranges,
+// __launch_bounds__(64, 6): left alone the compiler unrolls the 64 broadcast rounds with ~30 keys in flight and ends up
+// at 195 VGPRs = 2 waves per SIMD for a kernel that waits on dependent LDS probes; asked for 6 waves per SIMD (<= 80
+// VGPRs) the sort takes 37 us instead of 55 at C3 (measured: 3 / 4 / 6 / 8 waves -> 92 / 87 / 85 / 92 us for
+// gs_map_finish).
+__global__ __launch_bounds__(64, 6) void tile_rank_sort_kernel(int num_tiles, const int2* tile_ranges,
                                                             uint64_t* pairs, int* o2p, uint64_t* keys_out,
                                                             int depth16, int skip_full) {
   __shared__ uint64_t s_key[64 * RMAX];
