@@ -285,11 +285,12 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           S[3] += Gtx * tx; S[4] += Gtx * ty; S[5] += Gty * ty;
           if (HEUR) {
             // backward.py:194-198 from the lean record: dp/dmean = p (tx A + ty B), A = axis / sx, B = perp(axis) / sy
-            const float aag = g1v.z * alpha_grad;
-            // the staged frame and tx, ty both carry K_EXP: dp/dmean = p (tx A + ty B) / K_EXP^2
-            const float dmx = p * IK2 * (tx * g0v.z + ty * g1v.x), dmy = p * IK2 * (tx * g0v.w + ty * g1v.y);
+            const float aag = g1v.z * alpha_grad;  // alpha_grad is hit-masked in this mode
             S[6] += aag * aag;
-            S[7] += fabsf(aag * dmx) + fabsf(aag * dmy);
+            // |alpha_p dL/dalpha dp/dmean|_1 = |G| (|tx A.x + ty B.x| + |tx A.y + ty B.y|) / K_EXP^2 with
+            // G = alpha_p pdf dL/dalpha as above (the staged frame and tx, ty both carry K_EXP; the constant is
+            // applied once per splat in the epilogue)
+            S[7] += fabsf(G) * (fabsf(tx * g0v.z + ty * g1v.x) + fabsf(tx * g0v.w + ty * g1v.y));
           }
         }
       }
@@ -354,7 +355,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           row[4] = t[3] * isx;
           row[5] = t[5] * isy;
           row[6] = t[0] * gs_rcp_fast(al);
-          if (HEUR) { row[7 + FP] = t[6]; row[8 + FP] = t[7]; }
+          if (HEUR) { row[7 + FP] = t[6]; row[8 + FP] = t[7] * IK2; }
         }
 #pragma unroll
         for (int c = 0; c < FP; ++c) row[7 + c] = t[NS + c];
