@@ -217,7 +217,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       }
       if (VIS && a.vis) {
         // forward.py:116-128: per-splat visibility = sum of blend weights over the tile's pixels
-        if (__builtin_amdgcn_readfirstlane(__ballot(vis_sum != 0.0f) != 0ull)) {
+        if (__ballot(vis_sum != 0.0f) != 0ull) {  // wave-uniform by construction: a scalar compare of the ballot
           const float tot = gs_wave_sum_to_lane63(vis_sum);
           if (lane == 63) s_vis[j] = tot;  // each staged splat is visited once per round: a store, not a read-modify-write
         }
