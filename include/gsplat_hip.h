@@ -176,6 +176,9 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  * gs_map_finish means "not read back": its magnitude is only a hint for sizing the per-tile sort
  * (0 = no hint); fuller tiles are still sorted.  tile_order (optional, T int32) receives the tiles by
  * descending population: a launch order for gs_raster_fwd / gs_raster_bwd (heaviest tiles first).
+ * counts_host (optional): device-accessible pinned HOST memory, int32[5]; the scan kernel stores the four
+ * counts_out words and then *v_dev (0 without v_dev) there as well, so a caller that has to size buffers from K
+ * waits for an event recorded behind gs_map_prepare and reads them -- no device-to-host copy launch.
  * shard (optional, host pointer, read during the call): only the owned tile rows are mapped; num_tiles in
  * gs_map_scratch_bytes and the T of tile_ranges / tile_order are then the LOCAL tile count, sorted_keys carry local
  * tile ids.  Tile decisions are computed in full-image coordinates: the tiles of a shard get exactly the lists the
@@ -184,7 +187,8 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
 int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
-                   int32_t* tile_order, const GsRowShard* shard, void* scratch, int64_t scratch_bytes, void* stream);
+                   int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,
+                   int64_t scratch_bytes, void* stream);
 int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_count, const float* points,
                   const float* depth, int32_t width, int32_t height, const GsRasterConfig* cfg, int32_t use_depth16,
                   const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys, void* pair_scratch,

@@ -60,7 +60,7 @@ SIGNATURES = {
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
                                   _P]),
     "gs_map_scratch_bytes": (_I64, [_I64, _I64]),
-    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _SHARD, _P, _I64, _P]),
+    "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _SHARD, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,
                                       _P, _I64, _P]),
     "gs_tile_count": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P]),

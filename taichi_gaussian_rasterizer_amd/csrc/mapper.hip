@@ -163,7 +163,7 @@ __device__ __forceinline__ int block_exclusive_scan(int x, int* s_wave, int& sum
 // bin comes from LDS atomics and is arbitrary -- it only affects scheduling).
 __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int* tile_hist, int2* tile_ranges,
                                                         int* cursors, int* counts_out, int64_t k_capacity,
-                                                        int* tile_order) {
+                                                        int* tile_order, const int* v_dev, int* counts_host) {
   // workgroup 0: tile ranges, cursors, K / fullest tile / overflow; workgroup 1 (launched only with a tile_order):
   // the launch order and the heavy-tile count.  Both read the same histogram and neither waits for the other.
   __shared__ int s_wave[16];
@@ -204,10 +204,18 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
     if (t == 0) {
       int m = 0;
       for (int w = 0; w < 16; ++w) m = max(m, s_wave[w]);
+      const int over = (k_capacity > 0 && int64_t(carry) > k_capacity) ? 1 : 0;
       counts_out[0] = carry;
       counts_out[1] = m;
-      counts_out[2] = (k_capacity > 0 && int64_t(carry) > k_capacity) ? 1 : 0;
+      counts_out[2] = over;
       if (!tile_order) counts_out[3] = 0;
+      if (counts_host) {  // pinned host words, visible to the host once this kernel has completed: no copy launch
+        counts_host[0] = carry;
+        counts_host[1] = m;
+        counts_host[2] = over;
+        if (!tile_order) counts_host[3] = 0;
+        counts_host[4] = v_dev ? *v_dev : 0;
+      }
     }
     return;
   }
@@ -240,7 +248,11 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   // tiles with n > K / 1792 are the ones that bound it.  Large grids (K / 1792 above every tile) split nothing.
   {
     const int thr_bin = min(max(k_total / 1792, 96), 1022);
-    if (1023 - t == thr_bin) counts_out[3] = min(start, num_tiles / 4);  // tiles in bins above thr_bin
+    if (1023 - t == thr_bin) {
+      const int heavy = min(start, num_tiles / 4);  // tiles in bins above thr_bin
+      counts_out[3] = heavy;
+      if (counts_host) counts_host[3] = heavy;
+    }
   }
   __syncthreads();
   for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
@@ -990,8 +1002,8 @@ extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
 
 extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                               const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges,
-                              int32_t* counts_out, int32_t* tile_order, const GsRowShard* shard, void* scratch,
-                              int64_t scratch_bytes, void* stream) {
+                              int32_t* counts_out, int32_t* counts_host, int32_t* tile_order,
+                              const GsRowShard* shard, void* scratch, int64_t scratch_bytes, void* stream) {
   MapArgs a;
   if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0, shard)) return rc;
   a.v_dev = v_dev;
@@ -1031,7 +1043,8 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
   hipLaunchKernelGGL(map_scan_kernel, dim3(tile_order ? 2 : 1), dim3(1024), 0, s, num_tiles, hist,
-                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity, tile_order);
+                     reinterpret_cast<int2*>(tile_ranges), cursors, counts_out, k_capacity, tile_order, v_dev,
+                     counts_host);
   GS_CHECK_LAUNCH("gs_map_prepare/scan");
   return GS_OK;
 }

@@ -112,7 +112,8 @@ class _FusedRender(torch.autograd.Function):
         def no_rows():
             # this rank owns no tile row (more ranks than rows): nothing to map or rasterize, only V is needed
             counts[4:8] = 0
-            host_counts.copy_(counts, non_blocking=True)
+            host_counts[:4].copy_(counts[4:8], non_blocking=True)
+            host_counts[4:5].copy_(counts[0:1], non_blocking=True)
             ready.record()
             return (torch.empty((0,), dtype=torch.int32, device=dev), torch.empty((0, w, F), **f32),
                     torch.empty((0, w), **f32), torch.zeros((n,), **f32) if want_vis else None)
@@ -121,15 +122,14 @@ class _FusedRender(torch.autograd.Function):
             if num_tiles == 0:
                 return no_rows()
             nv.check(lib.gs_map_prepare(n, v_dev, nv.ptr(points), w, full_h, cfg, k_cap, nv.ptr(tile_ranges),
-                                        _off(counts, 4), nv.ptr(tile_order), sh, nv.ptr(mscratch), mbytes, s),
-                     "gs_map_prepare")
-            # V, K and the overflow flag are final here: copy them out asynchronously and keep enqueueing;
-            # the host waits on this event while the sort and the rasterizer are still running
-            host_counts.copy_(counts, non_blocking=True)
+                                        _off(counts, 4), nv.ptr(host_counts), nv.ptr(tile_order), sh,
+                                        nv.ptr(mscratch), mbytes, s), "gs_map_prepare")
+            # K, the overflow flag and V are final here and the scan kernel has stored them into the pinned host words
+            # itself (no copy launch): the host waits on this event while the sort and the rasterizer are still running
             ready.record()
             if k_cap == 0:  # first frame of this shape: K has to be known to size the buffers
                 ready.synchronize()
-                k_cap = max(int(host_counts[4]), 1)
+                k_cap = max(int(host_counts[0]), 1)
             o2p = torch.empty((k_cap,), dtype=torch.int32, device=dev)
             pairs = torch.empty((k_cap,), dtype=torch.int64, device=dev)
             nv.check(lib.gs_map_finish(n, v_dev, k_cap, tile_hint, nv.ptr(points), nv.ptr(ndc), w, full_h, cfg,
@@ -148,7 +148,7 @@ class _FusedRender(torch.autograd.Function):
         o2p, image, alpha, vis = map_and_raster(k_cap)
         ready.synchronize()  # waits for the mapper's scan only, not for the rasterizer
         host = host_counts.tolist()
-        V, K, max_tile, overflow = host[0], host[4], host[5], host[6]
+        K, max_tile, overflow, V = host[0], host[1], host[2], host[4]  # [3] = heavy tiles, device-side only
         if overflow:  # more overlaps than the hint allowed for: run the tail again with exact sizes
             o2p, image, alpha, vis = map_and_raster(max(K, 1))
             ready.synchronize()

@@ -69,7 +69,7 @@ def map_to_tiles(gaussians: torch.Tensor, depth: torch.Tensor, image_size: Tuple
     nbytes = lib.gs_map_scratch_bytes(v, num_tiles)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
     nv.check(lib.gs_map_prepare(v, None, nv.ptr(g), w, h, cfg, 0, nv.ptr(tile_ranges), nv.ptr(counts), None,
-                                None, nv.ptr(scratch), nbytes, nv.stream()), "gs_map_prepare")
+                                None, None, nv.ptr(scratch), nbytes, nv.stream()), "gs_map_prepare")
     k, max_tile = (int(x) for x in counts[:2].tolist())  # host sync (reference: full_cumsum.cu:45)
     overlap_to_point = torch.empty((k,), dtype=torch.int32, device=dev)
     keys = torch.empty((k,), dtype=torch.int64, device=dev) if return_keys else None

@@ -72,7 +72,7 @@ def test_row_shard_argument_is_validated():
     assert ctypes.sizeof(_native.GsRowShard) == 20 and ctypes.sizeof(_native.GsRasterConfig) == 60
 
     def prepare(shard):
-        return lib.gs_map_prepare(0, None, None, 64, 64, cfg, 0, None, None, None, ctypes.byref(shard), None, 0, None)
+        return lib.gs_map_prepare(0, None, None, 64, 64, cfg, 0, None, None, None, None, ctypes.byref(shard), None, 0, None)
 
     assert prepare(_native.GsRowShard(0, 9, 4, 1, 0)) == -1 and b"tile rows" in lib.gs_last_error()     # 64 px = 4 rows
     assert prepare(_native.GsRowShard(1, 3, 1, 2, 0)) == -1 and b"interleaved" in lib.gs_last_error()   # must span all
