@@ -234,6 +234,30 @@ __device__ __forceinline__ float gs_wave_reduce_transposed(float (&v)[N], int la
   return d;
 }
 
+// N = 9 (six moments + three colour gradients, the lean backward at F = 3): the ninth value would ride the butterfly
+// alone through both swap stages (a v_permlane swap costs 3 plain instructions); six fused DPP adds take it to row 3
+// instead, where lane 60 -- not an owner in the 8-value layout -- picks it up.
+template <>
+__device__ __forceinline__ int gs_reduce_slot<9>(int lane) {
+  return lane == 60 ? 8 : gs_reduce_slot<8>(lane);
+}
+
+template <>
+__device__ __forceinline__ float gs_wave_reduce_transposed<9>(float (&v)[9], int lane) {
+  float w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) w[i] = v[i];
+  float x = v[8];
+  x = gs_dpp_add_full<0x128>(x);  // row_ror:8
+  x = gs_dpp_add_full<0x124>(x);  // row_ror:4
+  x = gs_dpp_add_full<0x122>(x);  // row_ror:2
+  x = gs_dpp_add_full<0x121>(x);  // row_ror:1 -> every lane holds its row's sum
+  x = gs_dpp_add_full<0x142>(x);  // row_bcast:15: rows 1..3 add the row in front of them
+  x = gs_dpp_add_full<0x143>(x);  // row_bcast:31: rows 2, 3 add (row 0 + row 1) -> row 3 holds the total
+  const float d = gs_wave_reduce_transposed<8>(w, lane);
+  return lane == 60 ? x : d;
+}
+
 __device__ __forceinline__ float gs_exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
 __device__ __forceinline__ float gs_rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32 (1 ulp)
 
