@@ -79,10 +79,11 @@ struct BwdShape {
   static constexpr int NS = MODE == 2 ? 9 : MODE == 1 ? 8 : 6;
   static constexpr int NACC = NS + FP;           // values reduced per splat
   static constexpr int ROW = ((9 + FP + 15) / 16) * 16;
-  static constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
-  static constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
+  static constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s of geometry per staged record ...
+  static constexpr int REC_V4 = GEO_V4 + (FP + 3) / 4;  // ... followed by the feature row: one address, b128 reads
+  static constexpr int REC_F = 64 * 4 * REC_V4, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
   static constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
-  static constexpr int ARENA_F = (GEO_F + FEAT_F + ACC_F) > OUT_F ? (GEO_F + FEAT_F + ACC_F) : OUT_F;
+  static constexpr int ARENA_F = (REC_F + ACC_F) > OUT_F ? (REC_F + ACC_F) : OUT_F;
 };
 
 template <int NB, int FP, int MODE>
@@ -97,12 +98,11 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   // One LDS arena per wave.  The staged records (geo, feat) and the per-splat totals (acc) are dead
   // by the time the gradient rows (out) are written, so `out` aliases them: ~7.4 KB per wave
   // instead of ~11.5 KB, i.e. 21 instead of 13 resident waves per CU.
-  constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s per staged record
-  constexpr int GEO_F = 64 * 4 * GEO_V4, FEAT_F = 64 * FP, ACC_STRIDE = NACC + 1;
-  constexpr int OUT_STRIDE = ROW + 1;  // the arena itself is sized by BwdShape (same formulas)
-  float4(*s_geo)[GEO_V4] = reinterpret_cast<float4(*)[GEO_V4]>(smem);
-  float(*s_feat)[FP] = reinterpret_cast<float(*)[FP]>(smem + GEO_F);
-  float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + GEO_F + FEAT_F);
+  typedef BwdShape<FP, MODE> Shape;
+  constexpr int GEO_V4 = Shape::GEO_V4, REC_V4 = Shape::REC_V4, ACC_STRIDE = Shape::ACC_STRIDE;
+  constexpr int OUT_STRIDE = Shape::OUT_STRIDE;
+  float4(*s_geo)[REC_V4] = reinterpret_cast<float4(*)[REC_V4]>(smem);
+  float(*s_acc)[ACC_STRIDE] = reinterpret_cast<float(*)[ACC_STRIDE]>(smem + Shape::REC_F);
   float(*s_out)[OUT_STRIDE] = reinterpret_cast<float(*)[OUT_STRIDE]>(smem);
 
   // which value of the per-splat reduction this lane ends up owning (lane-constant; -1 = none)
@@ -183,7 +183,12 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       s_idx[lane] = idx;
       const float* f = a.features + int64_t(idx) * a.F;
 #pragma unroll
-      for (int c = 0; c < FP; ++c) s_feat[lane][c] = c < a.F ? f[c] : 0.0f;
+      for (int q = 0; q < REC_V4 - GEO_V4; ++q) {
+        float fv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fv[k] = (4 * q + k < FP && 4 * q + k < a.F) ? f[4 * q + k] : 0.0f;
+        s_geo[lane][GEO_V4 + q] = make_float4(fv[0], fv[1], fv[2], fv[3]);
+      }
     }
 #pragma unroll
     for (int c = 0; c < NACC; ++c) s_acc[lane][c] = 0.0f;
@@ -196,7 +201,13 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       if (FULL) g2v = s_geo[j][2];
       float feat[FP];
 #pragma unroll
-      for (int c = 0; c < FP; ++c) feat[c] = s_feat[j][c];
+      for (int q = 0; q < REC_V4 - GEO_V4; ++q) {
+        const float4 fq = s_geo[j][GEO_V4 + q];
+        const float fv[4] = {fq.x, fq.y, fq.z, fq.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * q + k < FP) feat[4 * q + k] = fv[k];
+      }
 
       float S[NS], gf[FP];
 #pragma unroll
@@ -261,8 +272,6 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         // T and R are updated so that both updates happen in place (no register copies at the end of the block).
         const float num = Tr[b] * dot - R[b];
         const float w = alc * Tr[b];
-        Tr[b] -= w;
-        R[b] -= w * dot;
         float alpha_grad = num * gs_rcp_fast(1.0f - alc);
         if (FULL || HEUR) alpha_grad = hit ? alpha_grad : 0.0f;  // these also use it without the a_hit factor
 #pragma unroll
@@ -293,6 +302,10 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
             S[7] += fabsf(G) * (fabsf(tx * g0v.z + ty * g1v.x) + fabsf(tx * g0v.w + ty * g1v.y));
           }
         }
+        // T -= alpha T and R -= w dot, last and in place: left to the scheduler, the new values are formed early in
+        // temporaries (the old ones are still needed for `num`) and copied back with two v_mov_b32 per block
+        asm("v_fma_f32 %0, -%0, %1, %0" : "+v"(Tr[b]) : "v"(alc));
+        asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(R[b]) : "v"(dot), "v"(w));
       }
 
       // reduce over the wave only if some pixel took a gradient (backward.py:204)
