@@ -82,8 +82,10 @@ __device__ __forceinline__ void aa_axis(float t, float inv_sigma, float& num, fl
 // 2: runtime switches for quantile mode / antialias (+ visibility).
 template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0, int yout0,
-                                                float4 (*s_geo)[MODE == 2 ? 3 : 2], float (*s_feat)[FP], float* s_vis,
+                                                float4 (*s_geo)[(MODE == 2 ? 3 : 2) + (FP + 3) / 4], float* s_vis,
                                                 int* s_idx) {
+  // staged record of a splat: GEO_V4 float4s of geometry, then its feature row (one LDS address, b128 reads)
+  constexpr int GEO_V4 = MODE == 2 ? 3 : 2, FEAT_V4 = (FP + 3) / 4;
   constexpr bool FULL = MODE == 2, VIS = MODE == 1 || MODE == 2, QUANT = MODE == 3;
   const bool blend = QUANT ? false : (FULL ? a.blend != 0 : true);
   const int lane = threadIdx.x;
@@ -156,7 +158,12 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       }
       const float* f = a.features + int64_t(idx) * a.F;
 #pragma unroll
-      for (int c = 0; c < FP; ++c) s_feat[lane][c] = c < a.F ? f[c] : 0.0f;
+      for (int q = 0; q < FEAT_V4; ++q) {
+        float fv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fv[k] = (4 * q + k < FP && 4 * q + k < a.F) ? f[4 * q + k] : 0.0f;
+        s_geo[lane][GEO_V4 + q] = make_float4(fv[0], fv[1], fv[2], fv[3]);
+      }
     }
     __syncthreads();  // single-wave workgroup: compiles to a wait on the LDS writes, no s_barrier
 
@@ -174,7 +181,13 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       r.g1 = s_geo[jj][1];
       if (FULL) r.g2 = s_geo[jj][2];
 #pragma unroll
-      for (int c = 0; c < FP; ++c) r.f[c] = s_feat[jj][c];
+      for (int q = 0; q < FEAT_V4; ++q) {
+        const float4 fq = s_geo[jj][GEO_V4 + q];
+        const float fv[4] = {fq.x, fq.y, fq.z, fq.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (4 * q + k < FP) r.f[4 * q + k] = fv[k];
+      }
     };
     auto blend_splat = [&](int j, const Rec& r) {
       const float4 g0v = r.g0, g1v = r.g1, g2v = FULL ? r.g2 : make_float4(0, 0, 0, 0);
@@ -257,8 +270,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 // bounds small grids (strips of a sharded frame, training-size images).  Without an order: XCD-contiguous bands.
 template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
-  __shared__ float4 s_geo[64][MODE == 2 ? 3 : 2];
-  __shared__ float s_feat[64][FP];
+  __shared__ float4 s_geo[64][(MODE == 2 ? 3 : 2) + (FP + 3) / 4];
   __shared__ float s_vis[(MODE == 1 || MODE == 2) ? 64 : 1];
   __shared__ int s_idx[(MODE == 1 || MODE == 2) ? 64 : 1];
   const int per_tile = a.sub_x * a.sub_y;
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
       int x0, y0, yout0;
       tile_origin(a, tile, x0, y0, yout0);
       x0 += (b & 1) * 8; y0 += ((b >> 1) & 1) * 8; yout0 += ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, s_geo, s_feat, s_vis, s_idx);
+      if (x0 < a.W && y0 < a.H) raster_fwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, s_geo, s_vis, s_idx);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(64) void raster_fwd_kernel(const FwdArgs a) {
   tile_origin(a, tile, x0, y0, yout0);
   x0 += (quad % a.sub_x) * RW; y0 += (quad / a.sub_x) * RH; yout0 += (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_fwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, s_geo, s_feat, s_vis, s_idx);
+  raster_fwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, s_geo, s_vis, s_idx);
 }
 
 template <int NB, int MODE>
