@@ -178,7 +178,8 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, r2, float(x0) + 0.5f - mx, float(y0) + 0.5f - my);
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
-      s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
+      // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
+      s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
       if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
       s_idx[lane] = idx;
       const float* f = a.features + int64_t(idx) * a.F;
@@ -244,7 +245,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         } else {
           tx = dx * g0v.z + dy * g0v.w;
           ty = dx * g1v.x + dy * g1v.y;
-          p = FULL ? gs_exp2_fast(-0.72134752044448170f * (tx * tx + ty * ty)) : gs_exp2_fast(-(tx * tx + ty * ty));
+          // lean: the record carries -log2(opacity), p is alpha itself (same expression as the forward: same bits)
+          p = FULL ? gs_exp2_fast(-0.72134752044448170f * (tx * tx + ty * ty))
+                   : gs_exp2_fast(-__builtin_fmaf(ty, ty, __builtin_fmaf(tx, tx, g1v.z)));
           if (FULL) {
             // taichi_lib/generic.py:321-336
             const float txs = tx * g2v.z, tys = ty * g2v.w;
@@ -256,7 +259,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
             dmy = p * (txs * g2v.y + tys * g2v.x);
           }
         }
-        const float alpha_raw = g1v.z * p;
+        const float alpha_raw = FULL ? g1v.z * p : p;
         const bool hit = alpha_raw > a.thr && Tr[b] > tsat;  // backward.py:160,166
         if (__ballot(hit) == 0ull) continue;
         any_grad = true;
@@ -294,8 +297,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           S[3] += Gtx * tx; S[4] += Gtx * ty; S[5] += Gty * ty;
           if (HEUR) {
             // backward.py:194-198 from the lean record: dp/dmean = p (tx A + ty B), A = axis / sx, B = perp(axis) / sy
-            const float aag = g1v.z * alpha_grad;  // alpha_grad is hit-masked in this mode
-            S[6] += aag * aag;
+            S[6] += alpha_grad * alpha_grad;  // hit-masked in this mode; the epilogue applies alpha_p^2
             // |alpha_p dL/dalpha dp/dmean|_1 = |G| (|tx A.x + ty B.x| + |tx A.y + ty B.y|) / K_EXP^2 with
             // G = alpha_p pdf dL/dalpha as above (the staged frame and tx, ty both carry K_EXP; the constant is
             // applied once per splat in the epilogue)
@@ -368,7 +370,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           row[4] = t[3] * isx;
           row[5] = t[5] * isy;
           row[6] = t[0] * gs_rcp_fast(al);
-          if (HEUR) { row[7 + FP] = t[6]; row[8 + FP] = t[7] * IK2; }
+          if (HEUR) { row[7 + FP] = t[6] * al * al; row[8 + FP] = t[7] * IK2; }
         }
 #pragma unroll
         for (int c = 0; c < FP; ++c) row[7 + c] = t[NS + c];

@@ -150,7 +150,8 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
                                      float(y0) + 0.5f - my);
       }
       s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
-      s_geo[lane][1] = make_float4(Bx, By, al, __int_as_float(mask));
+      // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
+      s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
       if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
       if (VIS) {
         s_vis[lane] = 0.0f;
@@ -198,7 +199,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
       for (int b = 0; b < NB; ++b) {
         if (!(mask & (1 << b))) continue;  // scalar branch
         const float dx = Xf[b] - g0v.x, dy = Yf[b] - g0v.y;
-        float p;
+        float p, alpha;
         if (FULL && a.aa) {
           // taichi_lib/generic.py:347-357
           const float tx = dx * g2v.x + dy * g2v.y, ty = dy * g2v.x - dx * g2v.y;
@@ -207,11 +208,16 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
           aa_axis(ty, g2v.w, ny, dy_);
           // tau sx sy D(tx) D(ty); sx sy = 1 / (isx isy) goes into the same reciprocal
           p = 6.28318530717958648f * nx * ny * gs_rcp_fast(dx_ * dy_ * g2v.z * g2v.w);
+          alpha = g1v.z * p;
         } else {
           const float tx = dx * g0v.z + dy * g0v.w, ty = dx * g1v.x + dy * g1v.y;
-          p = gs_exp2_fast(-(tx * tx + ty * ty));
+          if (FULL) {
+            alpha = g1v.z * gs_exp2_fast(-(tx * tx + ty * ty));
+          } else {
+            alpha = gs_exp2_fast(-__builtin_fmaf(ty, ty, __builtin_fmaf(tx, tx, g1v.z)));  // opacity * pdf
+          }
         }
-        const float al = __builtin_amdgcn_fmed3f(g1v.z * p, a.cmax, -1.0f);  // min(alpha, cmax) (forward.py:98-99)
+        const float al = __builtin_amdgcn_fmed3f(alpha, a.cmax, -1.0f);  // min(alpha, cmax) (forward.py:98-99)
         bool hit = al > a.thr;
         if (FULL || QUANT) hit = hit && !done[b];
         const float w = (hit ? al : 0.0f) * Tr[b];
