@@ -149,6 +149,19 @@ int gs_camera_position(const float* T_camera_world, float* camera_pos, void* str
 int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
               const float* positions, const int64_t* indexes, const float* camera_pos, float* out,
               int32_t out_stride, void* stream);
+/* Sharded frame (no reference counterpart): gs_sh_fwd for the rows whose splat can reach a tile row of
+ * `shard` (points2d (v,7) from gs_project_fwd; a superset of what gs_map_prepare lists for that shard); the other rows
+ * of `out` receive 0.5 ("not clamped").  shard == NULL evaluates the rows of the whole image's splats. */
+int gs_sh_fwd_shard(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
+                    const float* positions, const int64_t* indexes, const float* camera_pos, const float* points2d,
+                    int32_t height, const GsRasterConfig* cfg, const GsRowShard* shard, float* out,
+                    int32_t out_stride, void* stream);
+/* Sharded frame: split gs_raster_bwd's gradient rows (v, gs_grad_row_floats(F)) into the two packed arrays the ranks
+ * sum: splat_out (v, 7 + colour_col0) = columns [0, 7 + colour_col0) and colour_out (v, F - colour_col0) = the feature
+ * columns from colour_col0 on.  features (optional, (v,F): the forward's SH colours of THIS rank) zeroes the colour
+ * gradient of clamped channels before the sum -- required with gs_sh_fwd_shard, whose other rows are 0.5. */
+int gs_shard_pack_grads(int64_t v, int32_t num_features, int32_t colour_col0, const float* grad_rows,
+                        const float* features, float* colour_out, float* splat_out, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,

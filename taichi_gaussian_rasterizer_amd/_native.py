@@ -57,6 +57,8 @@ SIGNATURES = {
                                        _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "gs_camera_position": (ctypes.c_int, [_P, _P, _P]),
     "gs_sh_fwd": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
+    "gs_sh_fwd_shard": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _CFG, _SHARD, _P, _I32, _P]),
+    "gs_shard_pack_grads": (ctypes.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
                                   _P]),
     "gs_map_scratch_bytes": (_I64, [_I64, _I64]),

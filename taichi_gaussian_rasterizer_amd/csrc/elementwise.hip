@@ -62,7 +62,47 @@ __global__ __launch_bounds__(256) void feature_scatter_kernel(int64_t n, int C, 
   __builtin_nontemporal_store(slot >= 0 ? grad[int64_t(slot) * grad_stride + c] : 0.0f, d_features + e);
 }
 
+// Exchange buffers of a sharded frame: the rasterizer's gradient rows (V, row_floats) split into the two packed arrays
+// the ranks sum -- splat columns [0, 7 + col0) and colour columns [7 + col0, 7 + F) -- one element per thread, so both
+// sides are coalesced.  With `features` (the forward's SH colours, (V, F)) the colour gradient of a channel the forward
+// clamped is zeroed HERE, before the sum: only the ranks that rasterized a splat evaluated its colour
+// (gs_sh_fwd_shard), and every rank must end up with the same masked total.
+__global__ __launch_bounds__(256) void shard_pack_kernel(int64_t v, int F, int col0, const float* rows, int row_floats,
+                                                         const float* features, float* colour, float* splat) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int width = 7 + F;
+  const int64_t i = e / width;
+  if (i >= v) return;
+  const int c = int(e - i * width);
+  float g = rows[i * row_floats + c];
+  if (c < 7 + col0) {
+    splat[i * (7 + col0) + c] = g;
+  } else {
+    const int k = c - 7;  // feature column
+    if (features != nullptr) {
+      const float o = features[i * F + k];
+      if (!(o > 0.0f && o < 1.0f)) g = 0.0f;  // clamp sub-gradient (spherical_harmonics.py:118-134), as gs_sh_bwd's mask
+    }
+    colour[i * (F - col0) + (k - col0)] = g;
+  }
+}
+
 }  // namespace
+
+extern "C" int gs_shard_pack_grads(int64_t v, int32_t num_features, int32_t colour_col0, const float* grad_rows,
+                                   const float* features, float* colour_out, float* splat_out, void* stream) {
+  GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES && colour_col0 >= 0 && colour_col0 < num_features,
+             GS_ERR_INVALID_ARGUMENT, "gs_shard_pack_grads: %d features, colours from column %d", num_features,
+             colour_col0);
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(grad_rows && colour_out && splat_out, GS_ERR_INVALID_ARGUMENT, "gs_shard_pack_grads: NULL buffer");
+  const int64_t total = v * (7 + num_features);
+  hipLaunchKernelGGL(shard_pack_kernel, dim3(unsigned(gs_div_up(total, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), v, num_features, colour_col0, grad_rows,
+                     int(gs_grad_row_floats(num_features)), features, colour_out, splat_out);
+  GS_CHECK_LAUNCH("gs_shard_pack_grads");
+  return GS_OK;
+}
 
 extern "C" int gs_feature_gather_fwd(int64_t v, const int32_t* v_dev, int32_t channels, const float* features,
                                      const int64_t* indexes, float* out, int32_t out_stride, void* stream) {

@@ -63,6 +63,17 @@ GS_HD int gs_shard_global_row(const GsShard& s, int local) {
   return s.period == 1 ? local + s.begin : (local / s.band) * s.band * s.period + s.phase * s.band + local % s.band;
 }
 
+// does [lo, hi) hold a tile row of the shard?
+GS_HD bool gs_shard_any_row(const GsShard& s, int lo, int hi) {
+  lo = lo > s.begin ? lo : s.begin;
+  hi = hi < s.end ? hi : s.end;
+  if (lo >= hi) return false;
+  if (s.period == 1 || hi - lo >= s.band * s.period) return true;
+  for (int ty = lo; ty < hi; ++ty)
+    if ((ty / s.band) % s.period == s.phase) return true;
+  return false;
+}
+
 // validates `shard` against the image (NULL = whole image) and fills `out`
 static inline int gs_make_shard(const GsRowShard* shard, int rows, GsShard* out) {
   if (shard == nullptr) {

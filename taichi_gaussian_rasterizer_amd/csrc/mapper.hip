@@ -106,16 +106,7 @@ struct MapArgs {
   GsShard sh;           // owned tile rows (the whole image when the call is not sharded)
 };
 
-// does [lo, hi) hold a tile row of the shard?
-__device__ __forceinline__ bool any_owned_row(const GsShard& sh, int lo, int hi) {
-  lo = max(lo, sh.begin);
-  hi = min(hi, sh.end);
-  if (lo >= hi) return false;
-  if (sh.period == 1 || hi - lo >= sh.band * sh.period) return true;
-  for (int ty = lo; ty < hi; ++ty)
-    if ((ty / sh.band) % sh.period == sh.phase) return true;
-  return false;
-}
+__device__ __forceinline__ bool any_owned_row(const GsShard& sh, int lo, int hi) { return gs_shard_any_row(sh, lo, hi); }
 // local tile id of an owned tile
 __device__ __forceinline__ int local_tile(const MapArgs& a, int gx, int gy) {
   return gs_shard_local_row(a.sh, gy) * a.tiles_wide + gx;

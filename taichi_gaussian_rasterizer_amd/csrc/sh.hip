@@ -74,15 +74,44 @@ __device__ __forceinline__ void load_row(const float* row, float* out) {
   }
 }
 
+// Sharded frame: a rank evaluates the colours of the splats that can reach its tile rows only (the others are in none
+// of its tile lists).  The test is a superset of the mapper's: the row span of the ellipse's bounding box at the alpha
+// threshold (taichi_lib/grid_query.py:73-91), widened by two tile rows each way -- the reference's tile test checks the
+// ellipse's two axes only, so a tile just outside the bounding box can pass it (by less than one tile), and the margin
+// also makes the test independent of the last bit of either computation.
+struct ShTouch {
+  const float* points2d;  // (v, 7) projected splats, NULL = evaluate every row
+  GsShard sh;
+  float inv_tile, thr;
+  int tile_rows;
+};
+
+__device__ __forceinline__ bool sh_touched(const ShTouch& t, int64_t i) {
+  const float* g = t.points2d + i * 7;
+  const float my = g[1], ax = g[2], ay = g[3], sgx = g[4], sgy = g[5], alpha = g[6];
+  if (!(alpha > t.thr)) return false;  // in no tile list at all (mapper: explicit cull)
+  const float gscale = sqrtf(2.0f * __logf(alpha / t.thr)) * 1.001f;
+  const float v1y = ay * sgx, v2y = ax * sgy;
+  const float ey = sqrtf(v1y * v1y + v2y * v2y) * gscale;
+  const int lo = int(floorf((my - ey) * t.inv_tile)) - 2, hi = int(ceilf((my + ey) * t.inv_tile)) + 2;
+  return gs_shard_any_row(t.sh, max(lo, 0), min(hi, t.tile_rows));
+}
+
 // CT: channel count known at compile time (3: all loads of a Gaussian's rows are issued before the first use), 0: run-time C
 template <int DEG, int CT>
 __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev, int C, const float* params,
                                                      const float* positions, const int64_t* indexes,
-                                                     const float* cam, float* out, int out_stride) {
+                                                     const float* cam, float* out, int out_stride, const ShTouch touch) {
   constexpr int D = (DEG + 1) * (DEG + 1);
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (v_dev != nullptr && i >= *v_dev) return;
   if (i >= v) return;
+  if (touch.points2d != nullptr && !sh_touched(touch, i)) {
+    // never rasterized here; 0.5 = "not clamped" for gs_sh_bwd's mask (the owner ranks apply the real one before the
+    // gradients are summed: gs_shard_pack_grads)
+    for (int c = 0; c < C; ++c) out[i * out_stride + c] = 0.5f;
+    return;
+  }
   const int64_t idx = indexes[i];
   if (CT > 0) {
     float rows[CT > 0 ? CT : 1][D];
@@ -299,19 +328,20 @@ __global__ __launch_bounds__(256) void sh_bwd_dense_kernel(int64_t n, int C, con
 
 }  // namespace
 
-extern "C" int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
-                         const float* positions, const int64_t* indexes, const float* camera_pos, float* out,
-                         int32_t out_stride, void* stream) {
-  GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "gs_sh_fwd: SH degree %d not in [0,3]", degree);
-  GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "gs_sh_fwd: %d channels", channels);
+namespace {
+int sh_fwd_launch(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
+                  const float* positions, const int64_t* indexes, const float* camera_pos, float* out,
+                  int32_t out_stride, const ShTouch& touch, void* stream, const char* who) {
+  GS_REQUIRE(degree >= 0 && degree <= 3, GS_ERR_UNSUPPORTED, "%s: SH degree %d not in [0,3]", who, degree);
+  GS_REQUIRE(channels >= 1 && channels <= GS_MAX_SH_CHANNELS, GS_ERR_UNSUPPORTED, "%s: %d channels", who, channels);
   if (v == 0) return GS_OK;
-  GS_REQUIRE(params && positions && indexes && camera_pos && out, GS_ERR_INVALID_ARGUMENT, "gs_sh_fwd: NULL buffer");
+  GS_REQUIRE(params && positions && indexes && camera_pos && out, GS_ERR_INVALID_ARGUMENT, "%s: NULL buffer", who);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (out_stride <= 0) out_stride = channels;
   const dim3 grid(unsigned(gs_div_up(v, 256))), block(256);
 #define SH_FWD_C(DEG, CT)                                                                                         \
   hipLaunchKernelGGL((sh_fwd_kernel<DEG, CT>), grid, block, 0, s, v, v_dev, channels, params, positions, indexes, \
-                     camera_pos, out, out_stride)
+                     camera_pos, out, out_stride, touch)
 #define SH_FWD(DEG)                                                                                               \
   if (channels == 3) SH_FWD_C(DEG, 3);                                                                            \
   else SH_FWD_C(DEG, 0)
@@ -321,8 +351,34 @@ extern "C" int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int3
     case 2: SH_FWD(2); break;
     default: SH_FWD(3); break;
   }
-  GS_CHECK_LAUNCH("gs_sh_fwd");
+  GS_CHECK_LAUNCH(who);
   return GS_OK;
+}
+}  // namespace
+
+extern "C" int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
+                         const float* positions, const int64_t* indexes, const float* camera_pos, float* out,
+                         int32_t out_stride, void* stream) {
+  ShTouch touch{};
+  touch.points2d = nullptr;
+  return sh_fwd_launch(v, v_dev, channels, degree, params, positions, indexes, camera_pos, out, out_stride, touch,
+                       stream, "gs_sh_fwd");
+}
+
+extern "C" int gs_sh_fwd_shard(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
+                               const float* positions, const int64_t* indexes, const float* camera_pos,
+                               const float* points2d, int32_t height, const GsRasterConfig* cfg,
+                               const GsRowShard* shard, float* out, int32_t out_stride, void* stream) {
+  GS_REQUIRE(cfg && cfg->tile_size >= 1 && height >= 0, GS_ERR_INVALID_ARGUMENT, "gs_sh_fwd_shard: config / height");
+  GS_REQUIRE(points2d || v == 0, GS_ERR_INVALID_ARGUMENT, "gs_sh_fwd_shard: points2d is NULL");
+  ShTouch touch{};
+  touch.points2d = points2d;
+  touch.tile_rows = int(gs_div_up(height, cfg->tile_size));
+  if (int rc = gs_make_shard(shard, touch.tile_rows, &touch.sh)) return rc;
+  touch.inv_tile = 1.0f / float(cfg->tile_size);
+  touch.thr = cfg->alpha_threshold;
+  return sh_fwd_launch(v, v_dev, channels, degree, params, positions, indexes, camera_pos, out, out_stride, touch,
+                       stream, "gs_sh_fwd_shard");
 }
 
 #define SH_BWD_LAUNCH(DEG, UNIQ)                                                                                    \

@@ -90,7 +90,13 @@ class _FusedRender(torch.autograd.Function):
                                     nv.ptr(slot_of), nv.ptr(counts), nv.ptr(feats) if render_depth else None, F,
                                     nv.ptr(cam_pos), nv.ptr(pscratch), pbytes, s), "gs_project_fwd")
         v_dev = nv.ptr(counts)
-        if degree >= 0:
+        if degree >= 0 and shard is not None:
+            # a rank evaluates the colours of the splats that can reach its rows only (the replicated per-Gaussian
+            # stages are what bounds the scaling of a sharded frame); the other rows get the neutral 0.5
+            nv.check(lib.gs_sh_fwd_shard(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
+                                         nv.ptr(cam_pos), nv.ptr(points), full_h, cfg, sh,
+                                         _off(feats, col0), F, s), "gs_sh_fwd_shard")
+        elif degree >= 0:
             nv.check(lib.gs_sh_fwd(n, v_dev, C, degree, nv.ptr(feature), nv.ptr(position), nv.ptr(indexes),
                                    nv.ptr(cam_pos), _off(feats, col0), F, s), "gs_sh_fwd")
         else:
@@ -252,8 +258,12 @@ class _FusedRender(torch.autograd.Function):
             # ranks, 4*(7+F) bytes per visible Gaussian in all.  Two collectives, colour columns first: the SH
             # adjoint only needs those and runs while the splat columns are still in flight.
             from .parallel import _reduce_partial_gradients
-            pf = rows[:, 7 + col0:7 + F].contiguous()
-            pp = rows[:, :7 + col0].contiguous()
+            # (packed by one kernel, which also applies the SH clamp mask: only the ranks that rasterized a splat know it)
+            rows_n = rows.shape[0]
+            pf = torch.empty((rows_n, C), dtype=torch.float32, device=dev)
+            pp = torch.empty((rows_n, 7 + col0), dtype=torch.float32, device=dev)
+            nv.check(lib.gs_shard_pack_grads(rows_n, F, col0, nv.ptr(rows), nv.ptr(feats) if m["degree"] >= 0 else None,
+                                             nv.ptr(pf), nv.ptr(pp), s), "gs_shard_pack_grads")
             wait_points = _reduce_partial_gradients(pf, pp, m["group"])
             g_feat, g_feat_stride = nv.ptr(pf), C
             g_pts, g_pts_stride = pp, 7 + col0

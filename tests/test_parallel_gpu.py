@@ -75,3 +75,9 @@ def test_fused_sharded_frame_two_ranks(tmp_path, depth_mode, interleave, world, 
             ref = v.grad.cpu().numpy()
             err = np.linalg.norm(z[f"d_{k}"] - ref) / max(np.linalg.norm(ref), 1e-30)
             assert err < 1e-3, (rank, k, err)   # order of float sums differs (strips, collectives)
+            # exact zeros stay exact zeros: culled Gaussians, and colour channels the forward clamped -- a rank that
+            # did not rasterize a splat never evaluated its colour (gs_sh_fwd_shard), so the clamp mask reaches it
+            # only through the pre-masked gradient sum (gs_shard_pack_grads)
+            assert np.all(z[f"d_{k}"][ref == 0] == 0), (rank, k)
+    clamped = (g.feature.grad[:, :, 0] == 0).any(dim=1) & (g.feature.grad[:, :, 0] != 0).any(dim=1)
+    assert int(clamped.sum()) > 100  # the scene does exercise the mask: Gaussians with some channels clamped, some not
