@@ -48,6 +48,10 @@ def algorithmic_bytes(N, V, K, T, P, F, C, D):
     return {
         "gs_project_fwd": 44 * N + 64 * N + 48 * V + 4 * N,          # inputs, staging w+r, compact rows, slot map
         "gs_sh_fwd": V * (8 + 12 + 4 * C * D + 4 * C),
+        # sharded frame only: colours of the splats that reach the rank's rows (the caller scales by 1 / world), and the
+        # exchange buffers: gradient row + forward colours read, 4 (7 + F) packed bytes written
+        "gs_sh_fwd_shard": V * (28 + 8 + 12 + 4 * C * D + 4 * C),
+        "gs_shard_pack_grads": V * (64 + 4 * F + 4 * (7 + F)),
         "gs_map_prepare": 28 * V + 16 * T,
         "gs_map_finish": 32 * V + 8 * K + 8 * K + 4 * K + 8 * T,     # query again, bucket w, sort r, order w
         "gs_raster_fwd": 8 * T + K * (4 + 28 + 4 * F) + 4 * P * (F + 1),
@@ -271,7 +275,7 @@ def main():
                   file=sys.stderr)
         if dom in by:
             # under sharding a launch covers 1/world of the tiles: scale the per-launch bytes accordingly
-            per_launch = by[dom] / (world if dom.startswith(("gs_raster", "gs_map_finish")) else 1)
+            per_launch = by[dom] / (world if dom.startswith(("gs_raster", "gs_map_finish", "gs_sh_fwd_shard")) else 1)
             achieved = per_launch / (stages[dom]["avg_launch_ms"] * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
                             frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
