@@ -82,3 +82,22 @@ def test_row_shard_argument_is_validated():
     assert prepare(_native.GsRowShard(1, 3, 4, 1, 0)) == -1 and b"NULL buffer" in lib.gs_last_error()
     # an interleaved shard that deals every band to other owners: rows 0-3 in bands of 2 over 4 owners, owner 3
     assert prepare(_native.GsRowShard(0, 4, 2, 4, 3)) == -1 and b"owns no tile row" in lib.gs_last_error()
+
+
+def test_shard_only_entry_points_validate_on_the_host():
+    """gs_sh_fwd_shard / gs_shard_pack_grads (the sharded frame's own entry points): bad arguments are refused before
+    any launch, an empty call is a no-op"""
+    lib = _native.lib()
+    cfg = _native.GsRasterConfig(tile_size=16, alpha_threshold=1 / 255., forward_cut=2.0 ** -20)
+    shard = _native.GsRowShard(0, 9, 4, 1, 0)  # 64 px = 4 tile rows: row_end 9 is outside
+    rc = lib.gs_sh_fwd_shard(10, None, 3, 3, None, None, None, None, ctypes.c_void_p(16), 64, cfg,
+                             ctypes.byref(shard), None, 3, None)
+    assert rc == -1 and b"tile rows" in lib.gs_last_error()
+    rc = lib.gs_sh_fwd_shard(10, None, 3, 3, None, None, None, None, None, 64, cfg, None, None, 3, None)
+    assert rc == -1 and b"points2d" in lib.gs_last_error()
+    rc = lib.gs_sh_fwd_shard(10, None, 3, 7, None, None, None, None, ctypes.c_void_p(16), 64, cfg, None, None, 3, None)
+    assert rc == -2 and b"degree" in lib.gs_last_error()
+    assert lib.gs_sh_fwd_shard(0, None, 3, 3, None, None, None, None, None, 64, cfg, None, None, 3, None) == 0
+    assert lib.gs_shard_pack_grads(10, 3, 3, None, None, None, None, None) == -1     # colours must start inside the row
+    assert lib.gs_shard_pack_grads(10, 5, 2, None, None, None, None, None) == -1 and b"NULL" in lib.gs_last_error()
+    assert lib.gs_shard_pack_grads(0, 5, 2, None, None, None, None, None) == 0
