@@ -79,6 +79,9 @@ __device__ __forceinline__ void load_row(const float* row, float* out) {
 // threshold (taichi_lib/grid_query.py:73-91), widened by two tile rows each way -- the reference's tile test checks the
 // ellipse's two axes only, so a tile just outside the bounding box can pass it (by less than one tile), and the margin
 // also makes the test independent of the last bit of either computation.
+#ifndef GS_SH_ROW_MARGIN
+#define GS_SH_ROW_MARGIN 2
+#endif
 struct ShTouch {
   const float* points2d;  // (v, 7) projected splats, NULL = evaluate every row
   GsShard sh;
@@ -93,7 +96,7 @@ __device__ __forceinline__ bool sh_touched(const ShTouch& t, int64_t i) {
   const float gscale = sqrtf(2.0f * __logf(alpha / t.thr)) * 1.001f;
   const float v1y = ay * sgx, v2y = ax * sgy;
   const float ey = sqrtf(v1y * v1y + v2y * v2y) * gscale;
-  const int lo = int(floorf((my - ey) * t.inv_tile)) - 2, hi = int(ceilf((my + ey) * t.inv_tile)) + 2;
+  const int lo = int(floorf((my - ey) * t.inv_tile)) - GS_SH_ROW_MARGIN, hi = int(ceilf((my + ey) * t.inv_tile)) + GS_SH_ROW_MARGIN;
   return gs_shard_any_row(t.sh, max(lo, 0), min(hi, t.tile_rows));
 }
 

@@ -508,6 +508,30 @@ def test_sharded_strips_on_one_gpu(world):
     assert torch.allclose(torch.cat(strips2, 0), r.image.detach(), rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("interleave", [0, 1])
+def test_rank_local_sh_covers_every_listed_splat(interleave):
+    """gs_sh_fwd_shard evaluates colours only for the splats that can reach a rank's rows (0.5 elsewhere): its row test
+    must be a superset of the mapper's tile lists.  Long, thin, rotated splats over one-tile-row strips (16 ranks on a
+    256-px image, also dealt row by row) are the hard case -- the reference's tile test accepts tiles just outside a
+    splat's bounding box; every strip must still equal the rows of the unsharded image bit for bit."""
+    from taichi_gaussian_rasterizer_amd import parallel
+    size, n, world = (320, 256), 4000, 16
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=3, seed=11)
+    gen = torch.Generator().manual_seed(12)
+    g.log_scaling[:, 0] += 1.5 + torch.rand(n, generator=gen)     # 4.5 - 12 x longer along one axis
+    g.log_scaling[:, 1:] -= 0.7
+    cam = camera.to(device=DEV)
+    cfg = RasterConfig()
+    full = gs.render_gaussians(g.to(DEV), cam, cfg, use_sh=True)
+    rows = []
+    for rank in range(world):
+        rr = parallel.render_gaussians_sharded(g.to(DEV), cam, cfg, use_sh=True, rank=rank, world_size=world,
+                                               interleave=interleave)
+        assert torch.equal(rr.image, full.image[parallel.owned_pixel_rows(rr.bands).to(DEV)]), rank
+        rows.append(rr.image.shape[0])
+    assert sum(rows) == size[1]
+
+
 # ------------------------------------------- full-size properties (BASELINE config 3 shapes)
 def test_full_size_c3_properties():
     """1M Gaussians at 2048x2048, too large for the CPU oracle in a unit test: size-independent
