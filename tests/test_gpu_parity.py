@@ -72,6 +72,39 @@ def test_mapper_empty_and_culled():
     assert (pu.to_np(o2p) == ref_o2p).all() and (pu.to_np(ranges) == ref_ranges).all()
 
 
+def test_map_prepare_mirrors_its_counts_to_pinned_host_memory():
+    """gs_map_prepare(counts_host): the scan kernel stores {K, fullest tile, overflow, heavy tiles, *v_dev} into pinned
+    host words itself -- what the fused frame waits for instead of a device-to-host copy"""
+    import ctypes
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    torch.manual_seed(3)
+    n, size = 5000, (320, 200)
+    g2d = torch.cat([torch.rand(n, 1) * size[0], torch.rand(n, 1) * size[1], torch.tensor([[1.0, 0.0]]).expand(n, 2),
+                     torch.rand(n, 2) * 6 + 0.5, torch.rand(n, 1) * 0.6 + 0.3], 1).float()
+    depth = torch.rand(n, 1)
+    cfg = RasterConfig()
+    o2p_ref, ranges_ref = orc.map_to_tiles(g2d, depth, size, orc.OracleConfig.of(cfg))
+    lib = nv.lib()
+    tiles = ranges_ref.reshape(-1, 2).shape[0]
+    pts = dev(g2d)
+    ranges = torch.empty((tiles, 2), dtype=torch.int32, device=DEV)
+    counts = torch.full((4,), -7, dtype=torch.int32, device=DEV)
+    order = torch.empty((tiles,), dtype=torch.int32, device=DEV)
+    v_dev = torch.tensor([n - 100], dtype=torch.int32, device=DEV)   # live rows < capacity
+    host = torch.full((5,), -7, dtype=torch.int32).pin_memory()
+    nbytes = lib.gs_map_scratch_bytes(n, tiles)
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=DEV)
+    for k_cap in (0, 1000):  # unbounded, then a capacity that overflows
+        nv.check(lib.gs_map_prepare(n, nv.ptr(v_dev), nv.ptr(pts), size[0], size[1], nv.make_config(cfg), k_cap,
+                                    nv.ptr(ranges), nv.ptr(counts), nv.ptr(host), nv.ptr(order), None, nv.ptr(scratch),
+                                    nbytes, nv.stream()), "gs_map_prepare")
+        torch.cuda.synchronize()
+        assert host[:4].tolist() == counts.tolist() and int(host[4]) == n - 100
+        assert int(host[2]) == (1 if k_cap else 0)
+    o2p_live, _ = orc.map_to_tiles(g2d[:n - 100], depth[:n - 100], size, orc.OracleConfig.of(cfg))
+    assert int(host[0]) == o2p_live.shape[0]
+
+
 def test_hip_lib_cumsum_and_sort():
     rng = np.random.default_rng(0)
     for n in (1, 2, 1023, 1024, 1025, 100000, 1 << 20):
