@@ -182,6 +182,37 @@ def test_raster_forward_backward(seed, n, size, tile, F):
     pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
 
 
+@pytest.mark.parametrize("heur", [False, True])
+def test_raster_extreme_opacities(heur):
+    """the lean kernels stage -log2(opacity) and let v_exp_f32 return alpha: opacities at the threshold, at and beyond
+    the clamp (0.99) and above 1 (a caller's own 2D splats may carry any value) against the oracle's
+    opacity * exp(...) -- forward, backward and (heur) the densification statistics of the MODE 1 kernels"""
+    size, n, F = (96, 64), 600, 3
+    g2d, depth, feat = pu.make_2d_scene(21, n, size, channels=F, scale_factor=0.6)
+    cfg = RasterConfig(compute_point_heuristic=heur)
+    thr = cfg.alpha_threshold
+    vals = np.array([thr * (1 - 1e-3), thr * (1 + 1e-3), thr * 1.5, 0.05, 0.5, 0.98, 0.99, 0.995, 1.0, 1.5, 4.0],
+                    np.float32)
+    g2d = pu.to_np(g2d).copy()
+    g2d[:, 6] = vals[np.arange(n) % len(vals)]
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
+    pu.assert_pixels_close(out.image, image_ref, "image")
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(22))
+    (out.image * dev(gi)).sum().backward()
+    gg, gf, heur_ref = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p, ranges, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
+    assert torch.isfinite(g_t.grad).all() and float(g_t.grad[::len(vals)].abs().max()) == 0.0  # below the threshold
+    if heur:
+        pu.assert_grad_close(out.point_heuristic, heur_ref, "point_heuristic", tol=1e-3)
+
+
 @pytest.mark.parametrize("nb", [1, 2, 4])
 @pytest.mark.parametrize("seed,n,size,tile,F", [(11, 3000, (200, 120), 16, 3), (12, 2000, (160, 96), 32, 5)])
 def test_raster_wave_region_variants(nb, seed, n, size, tile, F, monkeypatch):
