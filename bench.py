@@ -18,9 +18,9 @@ Rank 0 prints ONE JSON line.  Beyond the driver's contract it carries
   roofline     : the dominant kernel's achieved algorithmic bytes/s (HIP events on the launch stream
                  inside the timed region) against the 8 TB/s HBM peak,
   cpu_baseline : the CPU oracle (oracle/, "port" of the same algorithm, OpenMP) timed on this host,
-  stages_ms    : per C-ABI entry point GPU time per step (separate untimed pass of 20 frames BEFORE the W warm-up
-                 steps; it also brings the GPU to its sustained clocks, so that short W / K settings still measure
-                 the steady state).
+  stages_ms_untimed_pass : per C-ABI entry point GPU time per step (separate untimed pass of 20 frames BEFORE the W
+                 warm-up steps, reported as "pre_warm_frames"; it also brings the GPU to its sustained clocks, so that
+                 short W / K settings still measure the steady state).
 Defaults: K = 100, W = 20 (SURVEY 8d asks for >= 50 iterations after >= 10 warm-ups); the default run takes about 20 s,
 most of it scene generation and the CPU baseline.
 """
@@ -290,7 +290,7 @@ def main():
             per_launch = by[dom] / (world if dom.startswith(("gs_raster", "gs_map_finish", "gs_sh_fwd_shard")) else 1)
             achieved = per_launch / (stages[dom]["avg_launch_ms"] * 1e-3) / 1e9
             roofline = dict(bound="hbm", kernel=dom, achieved=round(achieved, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None,
+                            frac=round(achieved / HBM_PEAK_GBS, 5), traffic=None, traffic_source=None,
                             algorithmic_bytes_per_launch=int(per_launch),
                             avg_launch_ms=round(stages[dom]["avg_launch_ms"], 4))
             pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -299,6 +299,8 @@ def main():
                     rec = json.load(open(pmc)).get(args.workload, {}).get(dom)
                     if rec and world == 1:
                         roofline["traffic"] = rec["hbm_bytes_per_launch"]  # FETCH_SIZE x2 (gfx950) + WRITE_SIZE
+                        roofline["traffic_source"] = ("profiles/pmc_traffic.json (static: rocprofv3 --pmc passes of "
+                                                      "this workload, not collected by this run)")
                         roofline["traffic_over_algorithmic"] = round(rec["hbm_bytes_per_launch"] / per_launch, 3)
                         if "valu_wave_insts_per_launch" in rec:
                             # the kernel is f32-VALU-issue-bound (no MFMA shape, HBM far from saturated): second
@@ -336,6 +338,8 @@ def main():
             "allreduce": allreduce,
             "steps": args.steps,
             "warmup": args.warmup,
+            # frames rendered BEFORE the W warm-up steps (the untimed per-stage pass, see the module docstring)
+            "pre_warm_frames": 0 if args.no_kernel_timing else STAGE_FRAMES,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True,
             "scaling": "strong",
@@ -346,6 +350,8 @@ def main():
                                    f"tile 16, {'fwd+bwd' if wl['backward'] else 'fwd'}"
                                    f"{', depth features' if wl['depth'] else ''}",
                        "visible": V, "overlaps": K, "tiles": T,
+                       # not a reference field: the forward's early stop (deviation 6) is ON in this number
+                       "forward_cut": cfg.forward_cut,
                        "backward_from": "fixed random dL/d(outputs), no loss kernels in the timed region"
                        if wl["backward"] else None,
                        "parallelism": "single GPU" if world == 1 else f"tile-row strips x{world} + grad all-reduce"},
@@ -357,7 +363,10 @@ def main():
                            "survey_8d_hbm_frac": round(sum(sv) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                            "note": "first pair: sum of the per-stage byte table above (what this implementation's "
                                    "stages must move); second pair: SURVEY.md 8(d) B_fwd + B_bwd on the measured V, K"},
-            "stages_ms": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items()) if "ms_per_step" in v},
+            # per entry point, from the untimed pre-warm pass with every entry point bracketed by events: NOT a
+            # decomposition of ms_per_step (the bracketing itself costs host time; the sum is a few % above it)
+            "stages_ms_untimed_pass": {k: round(v["ms_per_step"], 4) for k, v in sorted(stages.items())
+                                       if "ms_per_step" in v},
         }
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -382,7 +391,7 @@ def run_cpu_baseline(g_cpu, cam_cpu, cfg, wl, frames, gpu_image=None, gpu_overla
     best = None
     for _ in range(max(1, frames)):
         t0 = time.perf_counter()
-        out = pu.oracle_render(g_cpu, cam_cpu, cfg, use_sh=True, render_depth=wl["depth"], grads=grads)
+        out = pu.oracle_render(g_cpu, cam_cpu, cfg, use_sh=True, render_depth=wl["depth"], grads=grads, flips=False)
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     result = dict(value=round(W * H / best / 1e6, 3), unit="Mpix/s", cores=orc.num_threads(), kind="port",

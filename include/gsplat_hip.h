@@ -53,9 +53,11 @@ typedef struct GsRasterConfig {
   float saturate_threshold;
   /* Not a reference field.  The reference's forward keeps blending down a tile's whole list (forward.py:84-128);
    * this library stops a 16x16 region once EVERY pixel of it has less than forward_cut of its transmittance left.
-   * What is dropped changes a pixel by less than forward_cut * max|feature|.  0 reproduces the reference literally:
-   * values below 2^-25 act as 2^-25, half an ulp of 1, below which the reference's own f32 accumulation W += w no
-   * longer changes W (this library carries the transmittance T = 1 - W itself, which would keep shrinking).
+   * What is dropped changes a pixel by less than forward_cut * max|feature|.  0 is the setting closest to the
+   * reference: values below 2^-25 act as 2^-25, half an ulp of 1, below which the reference's own f32 accumulation
+   * W += w no longer changes W (this library carries the transmittance T = 1 - W itself, which would keep
+   * shrinking); the reference still adds alpha * (1 - W) * feature there with 1 - W stuck at ~2^-24, so the two differ
+   * by less than N * 2^-24 * max|feature| for N remaining splats (no reference fixture pins this).
    * The Python layer passes RasterConfig.forward_cut (default 2^-20), divided by the squared far plane when the
    * z / z^2 depth features are blended, so the bound is relative to the feature magnitude. */
   float forward_cut;

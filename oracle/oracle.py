@@ -17,6 +17,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libgsplat_oracle.so")
+# GS_ORACLE_LIB: load another build of the same source instead (the `make -C oracle asan` sanitizer build)
+_LIB_OVERRIDE = os.environ.get("GS_ORACLE_LIB")
 _lib = None
 
 
@@ -34,7 +36,7 @@ def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         build()
-        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib = ctypes.CDLL(os.path.abspath(_LIB_OVERRIDE) if _LIB_OVERRIDE else _LIB_PATH)
         _lib.orc_full_cumsum_i32.restype = ctypes.c_int64
         _lib.orc_num_threads.restype = ctypes.c_int
         _lib.orc_det_logf.restype = ctypes.c_float

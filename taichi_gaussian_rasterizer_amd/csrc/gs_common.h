@@ -294,8 +294,12 @@ __device__ __forceinline__ int gs_sub_block_mask(float Ax, float Ay, float Bx, f
     const float xn = __builtin_amdgcn_fmed3f(0.0f, xa, xb), yn = __builtin_amdgcn_fmed3f(0.0f, ya, yb);
     const float ys = __builtin_amdgcn_fmed3f(rxy * xn, ya, yb);  // best y on the edge x = xn
     const float xs = __builtin_amdgcn_fmed3f(ryx * yn, xa, xb);  // best x on the edge y = yn
-    const float q1 = sxx * xn * xn + 2.0f * sxy * xn * ys + syy * ys * ys;
-    const float q2 = sxx * xs * xs + 2.0f * sxy * xs * yn + syy * yn * yn;
+    // |t|^2 from the PROJECTED coordinates, as the per-pixel code forms it: the expanded quadratic
+    // sxx x^2 + 2 sxy x y + syy y^2 cancels by (sigma1 / sigma2)^2 for an elongated splat far from its mean (terms
+    // ~1e6 for a result ~10: an f32 error of ~0.1, far above the slack), the projections do not
+    const float t1x = Ax * xn + Ay * ys, t1y = Bx * xn + By * ys;
+    const float t2x = Ax * xs + Ay * yn, t2y = Bx * xs + By * yn;
+    const float q1 = t1x * t1x + t1y * t1y, q2 = t2x * t2x + t2y * t2y;
     if (fminf(q1, q2) <= lim) mask |= 1 << b;
   }
   return mask;

@@ -369,7 +369,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           row[3] = isy * tydx - isx * txdy;
           row[4] = t[3] * isx;
           row[5] = t[5] * isy;
-          row[6] = t[0] * gs_rcp_fast(al);
+          // G carries the opacity; a listed splat at or below the threshold (a caller's own tile lists may hold one:
+          // opacity zeroed after map_to_tiles) blended nothing, and 0 * rcp(0) must not become NaN
+          row[6] = al > a.thr ? t[0] * gs_rcp_fast(al) : 0.0f;
           if (HEUR) { row[7 + FP] = t[6] * al * al; row[8 + FP] = t[7] * IK2; }
         }
 #pragma unroll

@@ -114,8 +114,8 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
   for (int g0 = range.x; g0 < range.y; g0 += 64) {
     // The reference's forward never stops (forward.py:84-128).  Once every pixel of the region has less than
     // cfg->forward_cut of its transmittance left, everything still to come changes a pixel by less than
-    // forward_cut * max|feature| in total, so the rest of a crowded tile's list is skipped (forward_cut = 0: only
-    // where the f32 transmittance is exactly zero, i.e. every further weight is 0.0f -- the reference literally).
+    // forward_cut * max|feature| in total, so the rest of a crowded tile's list is skipped (forward_cut = 0 acts as
+    // 2^-25, see gs_raster_fwd: within N * 2^-24 * max|feature| of the reference for N remaining splats).
     // The same holds per 8x8 sub-block: a saturated one is masked out for the rest of the list.
     int live = 0;
     if (blend) {
@@ -360,8 +360,9 @@ extern "C" int gs_raster_fwd(int64_t v, int32_t num_features, const float* point
   if (cfg->tune_no_heavy_split) a.heavy = nullptr;
   a.cmax = cfg->clamp_max_alpha; a.thr = cfg->alpha_threshold; a.inv_thr = 1.0f / cfg->alpha_threshold;
   a.sat_level = 1.0f - cfg->saturate_threshold;
-  // below 2^-25 (half an ulp of 1) the reference's own f32 accumulation W += w no longer changes W: walking further
-  // would add what the reference drops, so that is where forward_cut = 0 ("the reference literally") stops
+  // below 2^-25 (half an ulp of 1) the reference's own f32 accumulation W += w no longer changes W, but it still adds
+  // alpha * (1 - W) * feature for every remaining splat with 1 - W stuck at ~2^-24; this kernel carries T itself and
+  // stops here: forward_cut = 0 differs from the reference by < N * 2^-24 * max|feature| (N remaining splats)
   a.cut = cfg->forward_cut > 2.98023223876953125e-08f ? cfg->forward_cut : 2.98023223876953125e-08f;
   a.blend = cfg->use_alpha_blending; a.vis = vis; a.aa = cfg->antialias;
   hipStream_t s = static_cast<hipStream_t>(stream);

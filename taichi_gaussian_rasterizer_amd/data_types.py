@@ -42,11 +42,14 @@ class RasterConfig:
     compute_point_heuristic: bool = False  # implies compute_visibility
     compute_visibility: bool = False
 
-    # NOT a reference field (keyword-only, so reference call sites are unaffected).  The reference's forward blends
-    # down a tile's whole list (rasterizer/forward.py:84-128); this forward stops a 16x16 region once every pixel of
-    # it has less than forward_cut of its transmittance left, which changes a pixel by < forward_cut * max|feature|.
-    # 0.0 reproduces the reference literally (the kernel then stops at 2^-25, where the reference's own f32 W += w
-    # stops changing W).  With render_depth the cut is divided by far^2 (the z^2 feature).
+    # NOT a reference field (the last one, with a default: reference call sites, which pass none of it, are
+    # unaffected).  The reference's forward blends down a tile's whole list (rasterizer/forward.py:84-128); this
+    # forward stops a 16x16 region once every pixel of it has less than forward_cut of its transmittance left, which
+    # changes a pixel by < forward_cut * max|feature|.  0.0 is the closest setting to the reference, not a literal
+    # reproduction: the kernel then stops at 2^-25, where the reference's own f32 W += w stops changing W, while the
+    # reference goes on adding alpha * (1 - W) * feature with 1 - W stuck at ~2^-24 -- a difference below
+    # (remaining splats) * 2^-24 * max|feature| that no reference fixture pins.  With render_depth the cut is divided
+    # by far^2 (the z^2 feature).
     forward_cut: float = 2.0 ** -20
 
     def __post_init__(self):

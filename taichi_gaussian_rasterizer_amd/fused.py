@@ -246,6 +246,19 @@ class _FusedRender(torch.autograd.Function):
             if g_depth is not None and V > 0 and m["render_depth"]:
                 pts_rows[:V, 7] += g_depth.reshape(-1)
 
+        def publish(pts_rows):
+            # `Rendering.gaussians2d` is an OUTPUT of this node, so autograd alone would leave its .grad without the
+            # rasterizer's dL/d(splat) (which never leaves the node).  The reference feeds that very tensor to
+            # rasterize, so `gaussians2d.retain_grad()` + `viewspace_gradient` (renderer.py:234-239) is the classic
+            # densification signal there: add the rasterizer's part (summed over the ranks of a sharded frame) to what
+            # the retain_grad hook has stored (this pass's upstream gradient, earlier backward passes) -- .grad
+            # accumulates over several backward passes as it does in the reference, and an empty view gets (0, 7).
+            out = ctx.holder.get("gaussians2d") if ctx.holder else None
+            out = out() if out is not None else None
+            if out is not None and out.retains_grad:
+                part = pts_rows[:V, :7].clone() if V > 0 else pts_rows.new_zeros((0, 7))
+                out.grad = part if out.grad is None else out.grad + part
+
         extra_depth = None
         if g_depth is not None and V > 0 and not m["render_depth"]:
             extra_depth = g_depth.contiguous()
@@ -268,6 +281,7 @@ class _FusedRender(torch.autograd.Function):
             g_feat, g_feat_stride = nv.ptr(pf), C
             g_pts, g_pts_stride = pp, 7 + col0
         else:
+            publish(rows)
             add_attached(rows)
 
         d_feature = torch.empty_like(feature)
@@ -287,15 +301,8 @@ class _FusedRender(torch.autograd.Function):
         if wait_points is not None:
             wait_points.wait()
         if m["shard"] is not None:
+            publish(g_pts)
             add_attached(g_pts)
-        # `Rendering.gaussians2d` is an OUTPUT of this node, so autograd alone would leave its .grad without the
-        # rasterizer's dL/d(splat) (which never leaves the node).  The reference feeds that very tensor to rasterize,
-        # so `gaussians2d.retain_grad()` + `viewspace_gradient` (renderer.py:234-239) is the classic densification
-        # signal there: publish the complete gradient (summed over the ranks of a sharded frame) on it.
-        out = ctx.holder.get("gaussians2d") if ctx.holder else None
-        out = out() if out is not None else None
-        if out is not None and out.retains_grad and V > 0:
-            out.grad = g_pts[:V, :7].clone()
 
         need_T, need_proj = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
         d_pos, d_ls = torch.empty_like(position), torch.empty_like(log_scaling)

@@ -55,6 +55,11 @@ class _Rows:
         if "v" not in st:
             st["v"] = torch.zeros_like(self.param)
             st["m"] = self.param.new_zeros(self.num_points) if self.per_row_moment else torch.zeros_like(self.param)
+        # a loaded state dict may hold non-contiguous moments: make the STATE contiguous once (the kernel updates the
+        # buffers it is handed in place; a temporary copy would be updated and dropped, freezing the moments)
+        for key in ("v", "m"):
+            if not st[key].is_contiguous():
+                st[key] = st[key].contiguous()
         return st["v"], st["m"]
 
     def shared(self, key: str) -> torch.Tensor:
@@ -73,11 +78,11 @@ def _launch(rows: _Rows, algorithm: int, indexes, weight, total_weight, grad, ro
     # a state dict from elsewhere may hold anything under these keys: the kernel indexes m[idx * D + j] and
     # v[idx] / v[idx * D + j] without further checks
     second = (rows.num_points,) if rows.per_row_moment else tuple(rows.param.shape)
-    assert tuple(m.shape) == tuple(rows.param.shape), \
-        f"{rows.name}: first moment (state['v']) has shape {tuple(m.shape)}, expected {tuple(rows.param.shape)}"
-    assert tuple(v.shape) == second, \
-        f"{rows.name}: second moment (state['m']) has shape {tuple(v.shape)}, expected {second}"
-    m, v = m.contiguous(), v.contiguous()
+    if tuple(m.shape) != tuple(rows.param.shape):
+        raise ValueError(f"{rows.name}: first moment (state['v']) has shape {tuple(m.shape)}, expected "
+                         f"{tuple(rows.param.shape)}")
+    if tuple(v.shape) != second:
+        raise ValueError(f"{rows.name}: second moment (state['m']) has shape {tuple(v.shape)}, expected {second}")
     nv.require_device(grad, weight, m, v, total_weight, scale, what="optimizer step")
     nv.require_device(indexes, dtype=torch.int64, what="optimizer step indexes")
     count, width = indexes.shape[0], rows.param.shape[1]

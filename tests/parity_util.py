@@ -8,33 +8,91 @@ from oracle import oracle as orc
 #   pixels:     |hip - oracle| <= ATOL + RTOL * |oracle|
 #   gradients:  normwise, max|hip - oracle| <= GRAD_TOL * max|oracle|  per tensor (sums of thousands
 #               of f32 terms in a different order; the reference itself only promises atomics order)
-# A bounded number of elements may exceed it: a pixel-splat pair whose alpha lies within an ulp of
-# alpha_threshold (or a pixel within an ulp of saturation) can fall on the other side of the
-# comparison when exp() differs in the last bit (v_exp_f32 vs glibc expf); each such flip moves a
-# pixel by at most ~alpha_threshold * |feature|.  Allowed: OUTLIER_FRAC of the elements, each
-# within OUTLIER_TOL.
+# There is NO blanket outlier budget (rounds 1-2 allowed 0.02 % of the elements to miss by up to 2e-2).  A pixel may
+# be outside the tolerance only when it is PROVEN to be an `alpha > alpha_threshold` decision (reference
+# rasterizer/forward.py:100) that two f32 implementations round to different sides: the oracle recomputes, per pixel, how
+# close its walk comes to the threshold (`orc.raster_flip_margin`, min |alpha - thr| / thr over the tile's splats); an
+# out-of-tolerance pixel must have a margin <= the bar and an error within what a few flips can cause (one flip moves
+# channel c by at most thr * T * |f_c|).
 ATOL = 2e-5
 RTOL = 2e-5
 GRAD_TOL = 2e-4
-OUTLIER_FRAC = 2e-4
-OUTLIER_TOL = 2e-2
+# |alpha - thr| / thr below which v_exp_f32 / fma contraction on the device and expf on the host may land on different
+# sides: the exponent tx^2 + ty^2 reaches ln(0.99 * 255) = 5.5 and carries ~4 roundings of 6e-8 relative each, i.e.
+# ~1.5e-6 absolute, plus one ulp of the exponential.  Stated bar: 5e-6 (measured on C2 / C3 / C4 at full size: every
+# out-of-tolerance pixel -- 1, 17 and 17 of them -- has a margin <= 1.2e-6).
+FLIP_MARGIN = 5e-6
+# end-to-end comparisons (GPU pipeline vs CPU pipeline): the two f32 projections differ in the last bits of the
+# projected mean and axes (~1e-4 px at 2048 px, relative 6e-8 of coordinates up to 2e3), which moves alpha by
+# |d ln alpha / dx| * 1e-4 = (r / sigma^2) * 1e-4 <= ~1e-3 relative for the sub-pixel sigmas of the test scenes
+E2E_FLIP_MARGIN = 2e-3
+MAX_FLIPS_PER_PIXEL = 3
 
 
 def to_np(x):
     return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
 
 
-def assert_pixels_close(hip, ref, name, atol=ATOL, rtol=RTOL):
+class FlipProof:
+    """what `assert_pixels_close` needs to accept an out-of-tolerance pixel: the oracle's per-pixel threshold margin,
+    the threshold, the largest |feature| a pixel blends per channel (scalar 1.0 for the weight image) and the bar"""
+
+    def __init__(self, margin, thr, feat_max=1.0, bar=FLIP_MARGIN):
+        self.margin, self.thr, self.feat_max, self.bar = margin, float(thr), feat_max, float(bar)
+
+    def channels(self, sl):
+        """the same proof for a channel slice of the rasterized image (e.g. image[..., 2:] of a depth render)"""
+        fm = self.feat_max[..., sl] if isinstance(self.feat_max, np.ndarray) else self.feat_max
+        return FlipProof(self.margin, self.thr, fm, self.bar)
+
+    def weight(self):
+        return FlipProof(self.margin, self.thr, 1.0, self.bar)
+
+
+def flip_proof(g2d, features, o2p, ranges, size, ocfg, bar=FLIP_MARGIN):
+    margin, fmax = orc.raster_flip_margin(to_np(g2d).astype(np.float32), o2p, ranges, size, ocfg,
+                                          features=to_np(features).astype(np.float32))
+    return FlipProof(margin, ocfg.alpha_threshold, fmax, bar)
+
+
+def assert_pixels_close(hip, ref, name, atol=ATOL, rtol=RTOL, flips=None, scale_atol=False, bound=True):
+    """every element within atol (* max(1, m) with scale_atol: m = the largest |feature| of that channel among the
+    splats the pixel blends -- the accumulated weight carries ~1e-6 of ABSOLUTE f32 rounding whatever the features are,
+    so for feature channels beyond [0, 1], z up to `far` and z^2 up to far^2, the absolute part scales with them) +
+    rtol |ref| -- or its pixel is a proven threshold flip (`flips`, module comment).  bound=False skips the size
+    check for images that are not linear in the blend (depth = I0 / w, the median-depth pass)."""
     hip, ref = to_np(hip).astype(np.float64), to_np(ref).astype(np.float64)
     assert hip.shape == ref.shape, f"{name}: shape {hip.shape} vs {ref.shape}"
+    assert np.isfinite(hip).all(), f"{name}: non-finite values"
+    squeeze = hip.ndim == 2
+    if squeeze:
+        hip, ref = hip[..., None], ref[..., None]
+    scale = 1.0
+    if flips is not None:
+        scale = np.maximum(np.broadcast_to(np.asarray(flips.feat_max, dtype=np.float64), hip.shape), 1.0)
     err = np.abs(hip - ref)
-    bad = err > atol + rtol * np.abs(ref)
-    nbad = int(bad.sum())
-    allowed = int(np.ceil(OUTLIER_FRAC * hip.size))
-    assert nbad <= allowed, f"{name}: {nbad} of {hip.size} elements out of tolerance (allowed {allowed}); max err {err.max():.3e}"
-    if nbad:
-        assert err[bad].max() <= OUTLIER_TOL * max(1.0, float(np.abs(ref).max())), \
-            f"{name}: outlier error {err[bad].max():.3e} exceeds {OUTLIER_TOL}"
+    tol = atol * (scale if scale_atol else 1.0) + rtol * np.abs(ref)
+    bad = err > tol
+    bad_px = bad.any(-1)
+    n_bad = int(bad_px.sum())
+    report = dict(outlier_pixels=n_bad, fraction=n_bad / max(bad_px.size, 1))
+    if n_bad == 0:
+        return report
+    assert flips is not None, (f"{name}: {int(bad.sum())} of {hip.size} elements out of tolerance; max err "
+                               f"{err.max():.3e} (no outlier budget: pass a FlipProof)")
+    m = flips.margin[bad_px]
+    report.update(max_margin_of_outliers=float(m.max()), max_err=float(err[bad].max()))
+    not_flips = int((m > flips.bar).sum())
+    assert not_flips == 0, (f"{name}: {not_flips} of {n_bad} out-of-tolerance pixels are NOT alpha-threshold flips "
+                            f"(their margin |alpha - thr| / thr is up to {float(m.max()):.3e} > {flips.bar}); "
+                            f"max err {err[bad].max():.3e}")
+    if bound:
+        limit = MAX_FLIPS_PER_PIXEL * flips.thr * scale * 1.01 + tol
+        worst = (err / limit).max()
+        assert worst <= 1.0, f"{name}: an outlier is {worst:.2f}x what {MAX_FLIPS_PER_PIXEL} threshold flips can cause"
+    # how many pixels COULD flip at all: the outliers must be a subset of them, which is what was just shown
+    report["pixels_with_margin_below_bar"] = int((flips.margin <= flips.bar).sum())
+    return report
 
 
 def assert_grad_close(hip, ref, name, tol=GRAD_TOL):
@@ -149,7 +207,7 @@ def cov_form(points):
 
 
 def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, use_depth16=False, grads=None,
-                  dtype=np.float32):
+                  dtype=np.float32, flips=True):
     """Full render_gaussians on the CPU oracle (f32; dtype=np.float64 runs every floating-point stage in double --
     the tile mapper stays f32, it has no other form in the reference either -- as the yardstick for comparisons
     between two f32 pipelines).  gaussians: Gaussians3D on CPU.
@@ -178,12 +236,16 @@ def oracle_render(gaussians, camera, config, use_sh=False, render_depth=False, u
     image, alpha, vis = orc.rasterize_with_tiles(points, feats_r, o2p, ranges, size, cfg)
     out = dict(points=points, depth=depth, indexes=idx, features=feats, o2p=o2p, ranges=ranges, alpha=alpha,
                visibility=vis, ndc=ndc)
+    # proof material for pixels that two f32 PIPELINES decide differently (projection rounding included)
+    # (flips=False: bench.py's cpu_baseline leg times this function and wants the path only)
+    proof = flip_proof(points, feats_r, o2p, ranges, size, cfg, bar=E2E_FLIP_MARGIN) if flips else None
     if render_depth:
         w = alpha + dtype(1e-6)
         d = image[..., 0] / w
-        out.update(image=image[..., 2:], depth_img=d, depth_var=image[..., 1] / w - d ** 2)
+        out.update(image=image[..., 2:], depth_img=d, depth_var=image[..., 1] / w - d ** 2,
+                   flips=proof.channels(slice(2, None)) if flips else None)
     else:
-        out.update(image=image)
+        out.update(image=image, flips=proof)
     if grads is None:
         return out
     # ---- backward chain

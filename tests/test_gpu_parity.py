@@ -169,8 +169,9 @@ def test_raster_forward_backward(seed, n, size, tile, F):
     g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
     out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
     assert tuple(out.image.shape) == (size[1], size[0], F) and tuple(out.image_weight.shape) == (size[1], size[0])
-    pu.assert_pixels_close(out.image, image_ref, "image")
-    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    proof = pu.flip_proof(g2d, feat, o2p, ranges, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "image", flips=proof)
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha", flips=proof.weight())
     torch.manual_seed(100 + seed)
     gi = torch.rand(size[1], size[0], F)
     (out.image * dev(gi)).sum().backward()
@@ -200,8 +201,9 @@ def test_raster_extreme_opacities(heur):
     image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
     g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
     out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
-    pu.assert_pixels_close(out.image, image_ref, "image")
-    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    proof = pu.flip_proof(g2d, feat, o2p, ranges, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "image", flips=proof)
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha", flips=proof.weight())
     gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(22))
     (out.image * dev(gi)).sum().backward()
     gg, gf, heur_ref = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
@@ -228,8 +230,9 @@ def test_raster_wave_region_variants(nb, seed, n, size, tile, F, monkeypatch):
     image_ref, alpha_ref, vis_ref = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
     g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
     out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
-    pu.assert_pixels_close(out.image, image_ref, "image")
-    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    proof = pu.flip_proof(g2d, feat, o2p, ranges, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "image", flips=proof)
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha", flips=proof.weight())
     if cfg.compute_visibility:
         pu.assert_grad_close(out.visibility, vis_ref, "visibility", tol=1e-5)
     gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(seed))
@@ -238,6 +241,71 @@ def test_raster_wave_region_variants(nb, seed, n, size, tile, F, monkeypatch):
     _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p, ranges, size, ocfg, gi)
     pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
     pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
+
+
+@pytest.mark.parametrize("nb", [1, 2, 4])
+def test_raster_antialias_gradients_at_scale(nb, monkeypatch):
+    """the antialiased pdf (taichi_lib/generic.py:341-404) beyond the reference's 8x8 gradcheck scene: tile 16,
+    >= 300 splats in EVERY tile (five or more staging groups per wave, saturation inside the lists), blur_cov = 0 as
+    the reference pairs it, all three wave-region shapes -- so the support-box sub-block masks
+    (gs_sub_block_mask_antialias) decide for every block of every tile.  Pixels vs the f32 oracle, gradients vs the f32
+    oracle with the f64 oracle as yardstick, at the suite's stated bars."""
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    monkeypatch.setitem(nv.TUNING, "wave_sub_blocks", int(nb))
+    size, n, F = (128, 96), 8000, 3
+    g2d, depth, feat = pu.make_2d_scene(31, n, size, channels=F, scale_factor=2.0)
+    cfg = RasterConfig(antialias=True, blur_cov=0.0)
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)
+    assert int((ranges[..., 1] - ranges[..., 0]).min()) >= 300
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
+    proof = pu.flip_proof(g2d, feat, o2p, ranges, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "antialias image", flips=proof)
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "antialias weight", flips=proof.weight())
+    gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(32))
+    (out.image * dev(gi)).sum().backward()
+    gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p, ranges, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "antialias grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "antialias grad_features")
+    pu.assert_rows_close(g_t.grad, gg64, "antialias grad_gaussians2d rows", tol=1e-2, frac=0.995)
+    pu.assert_rows_close(f_t.grad, gf64, "antialias grad_features rows", tol=1e-2, frac=0.995)
+
+
+@pytest.mark.parametrize("cfg_kw", [dict(), dict(compute_point_heuristic=True), dict(antialias=True, blur_cov=0.0)])
+def test_raster_listed_splats_without_opacity(cfg_kw):
+    """rasterize_with_tiles takes the CALLER'S tile lists (function.py:96-127), which may hold splats whose opacity was
+    zeroed or masked after map_to_tiles: opacity 0, a subnormal, and values at or below alpha_threshold.  Such a splat
+    blends nothing; its gradient row must be exactly zero and finite (the lean backward divides its opacity out of the
+    reduced sums), everything else as in the oracle."""
+    size, n, F = (96, 64), 500, 3
+    g2d, depth, feat = pu.make_2d_scene(41, n, size, channels=F, scale_factor=0.6)
+    cfg = RasterConfig(**cfg_kw)
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)          # lists built with every splat opaque enough
+    g2d = pu.to_np(g2d).copy()
+    dead = np.array([0.0, 1e-42, cfg.alpha_threshold * 0.5, cfg.alpha_threshold], np.float32)
+    g2d[:200, 6] = dead[np.arange(200) % 4]
+    assert np.isin(np.arange(200), o2p).all()                       # ... and the dead ones are listed
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p, ranges, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
+    proof = pu.flip_proof(g2d, feat, o2p, ranges, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "image", flips=proof)
+    gi = torch.rand(size[1], size[0], F, generator=torch.Generator().manual_seed(42))
+    (out.image * dev(gi)).sum().backward()
+    gg, gf, heur_ref = orc.rasterize_backward(g2d, feat, o2p, ranges, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    assert torch.isfinite(g_t.grad).all() and torch.isfinite(f_t.grad).all()
+    assert float(g_t.grad[:200].abs().max()) == 0.0 and float(f_t.grad[:200].abs().max()) == 0.0
+    assert float(np.abs(gg[:200]).max()) == 0.0
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p, ranges, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
+    if cfg.compute_point_heuristic:
+        assert torch.isfinite(out.point_heuristic).all()
+        pu.assert_grad_close(out.point_heuristic, heur_ref, "point_heuristic", tol=1e-3)
 
 
 @pytest.mark.parametrize("seed", range(3))
@@ -258,7 +326,8 @@ def test_raster_reference_gradcheck_scene(seed):
                                                    orc.OracleConfig.of(cfg))
         g_t, f_t = dev(g2d).requires_grad_(True), dev(g.feature.float()).requires_grad_(True)
         out = gs.rasterize_with_tiles(g_t, f_t, dev(o2p), dev(ranges), (8, 8), cfg)
-        pu.assert_pixels_close(out.image, image_ref, f"image aa={antialias}", atol=5e-5, rtol=5e-5)
+        proof = pu.flip_proof(g2d, g.feature.float(), o2p, ranges, (8, 8), orc.OracleConfig.of(cfg))
+        pu.assert_pixels_close(out.image, image_ref, f"image aa={antialias}", atol=5e-5, rtol=5e-5, flips=proof)
         gi = np.random.default_rng(seed).random((8, 8, channels)).astype(np.float32)
         (out.image * dev(gi)).sum().backward()
         gg, gf, _ = orc.rasterize_backward(g2d.double(), g.feature.double(), o2p, ranges, (8, 8), image_ref,
@@ -299,7 +368,9 @@ def test_quantile_mode_median_depth():
     o2p, ranges = orc.map_to_tiles(g2d, depth, size, ocfg)
     image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, depth, o2p, ranges, size, ocfg)
     out = gs.rasterize_with_tiles(dev(g2d), dev(depth), dev(o2p), dev(ranges.reshape(-1, 2)), size, cfg)
-    pu.assert_pixels_close(out.image, image_ref, "median depth")
+    # a flipped alpha decision moves the 0.5 crossing to another splat: the pixel then takes that splat's depth
+    proof = pu.flip_proof(g2d, depth, o2p, ranges, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "median depth", flips=proof, bound=False)
     assert (pu.to_np(out.image_weight) == alpha_ref).mean() > 0.999
 
 
@@ -445,13 +516,15 @@ def test_render_gaussians_stagewise(seed, n, size, deg, depth_mode):
     f_np = pu.to_np(feats)
     feats_r = np.concatenate([d_np, d_np ** 2, f_np], 1).astype(np.float32) if depth_mode else f_np
     image_ref, alpha_ref, _ = orc.rasterize_with_tiles(p_np, feats_r, o2p_ref, ranges_ref, size, ocfg)
+    proof = pu.flip_proof(p_np, feats_r, o2p_ref, ranges_ref, size, ocfg)
     g_img = np.zeros_like(image_ref)
     if depth_mode:
-        pu.assert_pixels_close(r.image, image_ref[..., 2:], "image")
+        pu.assert_pixels_close(r.image, image_ref[..., 2:], "image", flips=proof.channels(slice(2, None)))
         w = alpha_ref + np.float32(1e-6)
         d_img = image_ref[..., 0] / w
-        pu.assert_pixels_close(r.depth, d_img, "depth", atol=1e-4, rtol=1e-4)
-        pu.assert_pixels_close(r.depth_var, image_ref[..., 1] / w - d_img ** 2, "depth_var", atol=2e-3, rtol=1e-3)
+        pu.assert_pixels_close(r.depth, d_img, "depth", atol=1e-4, rtol=1e-4, flips=proof.weight(), bound=False)
+        pu.assert_pixels_close(r.depth_var, image_ref[..., 1] / w - d_img ** 2, "depth_var", atol=2e-3, rtol=1e-3,
+                               flips=proof.weight(), bound=False)
         hip_img = np.concatenate([pu.to_np(r.depth * (r.image_weight + 1e-6))[..., None],
                                   pu.to_np((r.depth_var + r.depth ** 2) * (r.image_weight + 1e-6))[..., None],
                                   pu.to_np(r.image)], -1)
@@ -461,10 +534,10 @@ def test_render_gaussians_stagewise(seed, n, size, deg, depth_mode):
         g_img[..., 0] = (gdm.numpy() - 2 * d_h * gvm.numpy()) / w_h
         g_img[..., 1] = gvm.numpy() / w_h
     else:
-        pu.assert_pixels_close(r.image, image_ref, "image")
+        pu.assert_pixels_close(r.image, image_ref, "image", flips=proof)
         hip_img = pu.to_np(r.image)
         g_img[...] = gi.numpy()
-    pu.assert_pixels_close(r.image_weight, alpha_ref, "image_weight")
+    pu.assert_pixels_close(r.image_weight, alpha_ref, "image_weight", flips=proof.weight())
     gg, gf, _ = orc.rasterize_backward(p_np, feats_r, o2p_ref, ranges_ref, size, hip_img.astype(np.float32), g_img, ocfg)
     gdepth_ref = np.zeros_like(d_np)
     if depth_mode:
@@ -505,8 +578,9 @@ def test_render_gaussians_end_to_end_vs_oracle(seed, n, size, deg, depth_mode):
     gd = g.to(DEV).requires_grad_(True)
     r = gs.render_gaussians(gd, camera.to(device=DEV), cfg, use_sh=True, render_depth=depth_mode)
     assert (pu.to_np(r.points_in_view) == ref["indexes"]).all()
-    pu.assert_pixels_close(r.image, ref["image"], "image", atol=1e-3, rtol=1e-3)
-    pu.assert_pixels_close(r.image_weight, ref["alpha"], "image_weight", atol=1e-3, rtol=1e-3)
+    pu.assert_pixels_close(r.image, ref["image"], "image", atol=1e-3, rtol=1e-3, flips=ref["flips"])
+    pu.assert_pixels_close(r.image_weight, ref["alpha"], "image_weight", atol=1e-3, rtol=1e-3,
+                           flips=ref["flips"].weight())
     (r.image * dev(gi)).sum().backward()
     relgap = np.full(n, np.inf)
     relgap[ref["indexes"]] = pu.relative_eigen_gap(ref["points"])
@@ -861,15 +935,18 @@ def test_render_gaussians_plain_features_median_depth_depth16_antialias():
         feats = np.concatenate([d_np, d_np ** 2, g.feature.numpy()[idx]], 1).astype(np.float32)
         image_ref, alpha_ref, _ = orc.rasterize_with_tiles(p_np, feats, o2p, ranges, size, ocfg)
         tol = dict(atol=2e-4, rtol=2e-4) if cfg.antialias else {}
-        pu.assert_pixels_close(r.image, image_ref[..., 2:], "image", **tol)
-        pu.assert_pixels_close(r.image_weight, alpha_ref, "weight", **tol)
+        proof = pu.flip_proof(p_np, feats, o2p, ranges, size, ocfg)
+        pu.assert_pixels_close(r.image, image_ref[..., 2:], "image", flips=proof.channels(slice(2, None)), **tol)
+        pu.assert_pixels_close(r.image_weight, alpha_ref, "weight", flips=proof.weight(), **tol)
         w = alpha_ref + np.float32(1e-6)
-        pu.assert_pixels_close(r.depth, image_ref[..., 0] / w, "depth", atol=1e-3, rtol=1e-3)
+        pu.assert_pixels_close(r.depth, image_ref[..., 0] / w, "depth", atol=1e-3, rtol=1e-3, flips=proof.weight(),
+                               bound=False)
         import dataclasses
         mcfg = orc.OracleConfig.of(dataclasses.replace(cfg, use_alpha_blending=False, saturate_threshold=0.5))
         med_ref, _, _ = orc.rasterize_with_tiles(p_np, d_np, o2p, ranges, size, mcfg)
         assert r.median_depth.shape == (size[1], size[0])
-        pu.assert_pixels_close(r.median_depth, med_ref[..., 0], "median depth", atol=1e-4, rtol=1e-4)
+        pu.assert_pixels_close(r.median_depth, med_ref[..., 0], "median depth", atol=1e-4, rtol=1e-4,
+                               flips=proof.weight(), bound=False)
         (r.image.sum() + r.depth.sum()).backward()
         assert gd.feature.grad.shape == g.feature.shape and bool(torch.isfinite(gd.position.grad).all())
         assert float(gd.feature.grad.abs().sum()) > 0
@@ -948,13 +1025,57 @@ def test_mapper_and_raster_with_huge_and_tiny_splats():
     image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p_ref, ranges_ref, size, ocfg)
     g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
     out = gs.rasterize_with_tiles(g_t, f_t, o2p, ranges.view(-1, 2), size, cfg)
-    pu.assert_pixels_close(out.image, image_ref, "image")
-    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha")
+    proof = pu.flip_proof(g2d, feat, o2p_ref, ranges_ref, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "image", flips=proof)
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha", flips=proof.weight())
     gi = torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(2))
     (out.image * dev(gi)).sum().backward()
     gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p_ref, ranges_ref, size, pu.to_np(out.image), gi.numpy(), ocfg)
-    pu.assert_grad_close(g_t.grad, gg, "grad_gaussians2d", tol=5e-4)
-    pu.assert_grad_close(f_t.grad, gf, "grad_features", tol=5e-4)
+    # the stated bar (2e-4), with the f64 oracle as the yardstick where the two f32 results part (deep blend lists)
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p_ref, ranges_ref, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
+
+
+@pytest.mark.parametrize("nb", [1, 4])
+def test_raster_needle_splats_across_many_tiles(nb, monkeypatch):
+    """100:1 ... 600:1 splats (sigma 300 x 0.5 px) crossing the whole image: a sub-block hundreds of pixels from the mean
+    along the long axis is reached only through a corridor one pixel wide.  The sub-block cull (gs_sub_block_mask) must
+    form |t|^2 there without the (sigma1 / sigma2)^2 cancellation of the expanded quadratic; a dropped block shows up
+    as missing pixels and missing gradient against the oracle, which evaluates every pixel of every listed tile."""
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    monkeypatch.setitem(nv.TUNING, "wave_sub_blocks", int(nb))
+    size, n, needles = (640, 400), 400, 60
+    rng = np.random.default_rng(17)
+    mean = rng.random((n, 2)) * np.array(size)
+    ang = rng.random(n) * 2 * np.pi
+    axis = np.stack([np.cos(ang), np.sin(ang)], 1)
+    sig = rng.uniform(2.0, 12.0, (n, 2))
+    sig[:needles] = np.stack([rng.uniform(150, 300, needles), rng.uniform(0.45, 1.5, needles)], 1)
+    mean[:needles // 2] += np.array(size) * rng.choice([-0.6, 0.6], (needles // 2, 2))  # means far outside the image
+    alpha = rng.uniform(0.3, 0.95, (n, 1))
+    g2d = np.concatenate([mean, axis, sig, alpha], 1).astype(np.float32)
+    depth = rng.random((n, 1)).astype(np.float32)
+    feat = rng.random((n, 3)).astype(np.float32)
+    cfg = RasterConfig()
+    ocfg = orc.OracleConfig.of(cfg)
+    o2p_ref, ranges_ref = orc.map_to_tiles(g2d, depth, size, ocfg)
+    o2p, ranges = gs.map_to_tiles(dev(g2d), dev(depth), size, cfg)
+    assert (pu.to_np(ranges) == ranges_ref).all() and (pu.to_np(o2p) == o2p_ref).all()
+    image_ref, alpha_ref, _ = orc.rasterize_with_tiles(g2d, feat, o2p_ref, ranges_ref, size, ocfg)
+    g_t, f_t = dev(g2d).requires_grad_(True), dev(feat).requires_grad_(True)
+    out = gs.rasterize_with_tiles(g_t, f_t, o2p, ranges.view(-1, 2), size, cfg)
+    proof = pu.flip_proof(g2d, feat, o2p_ref, ranges_ref, size, ocfg)
+    pu.assert_pixels_close(out.image, image_ref, "image", flips=proof)
+    pu.assert_pixels_close(out.image_weight, alpha_ref, "alpha", flips=proof.weight())
+    gi = torch.rand(size[1], size[0], 3, generator=torch.Generator().manual_seed(18))
+    (out.image * dev(gi)).sum().backward()
+    gg, gf, _ = orc.rasterize_backward(g2d, feat, o2p_ref, ranges_ref, size, pu.to_np(out.image), gi.numpy(), ocfg)
+    _, gg64, gf64 = pu.raster_truth(g2d, feat, o2p_ref, ranges_ref, size, ocfg, gi)
+    pu.assert_grad_close_vs_truth(g_t.grad, gg, gg64, "grad_gaussians2d")
+    pu.assert_grad_close_vs_truth(f_t.grad, gf, gf64, "grad_features")
+    # the needles themselves, row by row (a normwise bar is dominated by the round splats)
+    pu.assert_rows_close(g_t.grad[:needles], gg64[:needles], "needle rows", tol=2e-2, frac=0.95)
 
 
 # ------------------------------------------------------------------------------------- determinism

@@ -3,7 +3,7 @@
 for round in 1 2 3; do
   for lib in "$@"; do
     GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 2>/dev/null | python3 -c "
-import sys, json; d = json.loads(sys.stdin.read()); s = d['stages_ms']
+import sys, json; d = json.loads(sys.stdin.read()); s = d['stages_ms_untimed_pass']
 print('$lib', d['ms_per_step'], 'prepare', s.get('gs_map_prepare'), 'finish', s.get('gs_map_finish'))"
   done
 done

@@ -4,7 +4,7 @@ stage=$1; shift
 for round in 1 2 3; do
   for lib in "$@"; do
     GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 2>/dev/null | python3 -c "
-import sys, json; d = json.loads(sys.stdin.read()); s = d['stages_ms']
+import sys, json; d = json.loads(sys.stdin.read()); s = d['stages_ms_untimed_pass']
 print('$lib', d['ms_per_step'], '$stage', s.get('$stage'))"
   done
 done
