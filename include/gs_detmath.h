@@ -15,6 +15,14 @@
  *
  * Plain C (also valid C++/HIP).  No FMA is used, and callers compile with
  * -ffp-contract=off, so no contraction can change the rounding.
+ *
+ * gs_det_sqrtf: the correctly rounded square root.  On the host that is sqrtf.  On the device it is NOT
+ * `__fsqrt_rn`: hipcc's header maps that name to the native v_sqrt_f32 (1 ulp) unless OCML_BASIC_ROUNDED_OPERATIONS is
+ * defined -- rounds 1 and 2 used it, and C5 at its full size (6 M Gaussians) found the one splat in 5 million whose
+ * bounding box ends 2e-4 px past a tile edge in IEEE arithmetic and 1 ulp short of it with v_sqrt_f32 (two overlaps
+ * of 19 169 107 missing).  The device form below takes v_sqrt_f32 and settles the last bit with two exact fma
+ * residuals against the neighbouring floats (the scheme LLVM's own correctly rounded f32 sqrt lowering uses), so it does
+ * not depend on -fhip-fp32-correctly-rounded-divide-sqrt either.
  */
 #ifndef GS_DETMATH_H
 #define GS_DETMATH_H
@@ -77,6 +85,27 @@ GS_HD float gs_det_logf(float x) {
   float hfsq = (0.5f * f) * f;
   float dk = (float)k;
   return (s * (hfsq + R) + dk * ln2_lo) - hfsq + f + dk * ln2_hi;
+}
+
+/* Correctly rounded sqrt for x >= 0 (NaN / negative / inf as the native instruction returns them). */
+GS_HD float gs_det_sqrtf(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  /* below 2^-96 v_sqrt_f32's result would be subnormal-adjacent: scale by 2^32, unscale the root by 2^-16 */
+  const int tiny = x < 1.262177448e-29f; /* 2^-96 */
+  const float xs = tiny ? x * 4294967296.0f : x;
+  float r = __builtin_amdgcn_sqrtf(xs);
+  if (xs > 0.0f && xs < __builtin_huge_valf()) {
+    const float r_dn = gs_bits_f32(gs_f32_bits(r) - 1u), r_up = gs_bits_f32(gs_f32_bits(r) + 1u);
+    /* x - r_dn * r <= 0: the root lies at or below the midpoint of (r_dn, r) -> r_dn; x - r_up * r > 0: above the
+     * midpoint of (r, r_up) -> r_up (exact residuals: one rounding each, of a quantity whose sign is what matters) */
+    const float e_dn = __builtin_fmaf(-r_dn, r, xs), e_up = __builtin_fmaf(-r_up, r, xs);
+    if (e_dn <= 0.0f) r = r_dn;
+    if (e_up > 0.0f) r = r_up;
+  }
+  return tiny ? r * 1.52587890625e-05f : r; /* 2^-16 */
+#else
+  return __builtin_sqrtf(x);
+#endif
 }
 
 #endif /* GS_DETMATH_H */

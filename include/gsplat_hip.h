@@ -209,6 +209,11 @@ int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t max_tile_c
                   const int32_t* tile_ranges, int32_t* overlap_to_point, uint64_t* sorted_keys, void* pair_scratch,
                   const GsRowShard* shard, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* Diagnostic: the device forms of the two functions of include/gs_detmath.h the mapper's integer decisions rest on
+ * (correctly rounded sqrt, deterministic ln), element-wise, so that a test can hold them bit for bit against the
+ * host forms the CPU oracle is built from.  Either output may be NULL. */
+int gs_selftest_detmath(int64_t n, const float* x, float* sqrt_out, float* log_out, void* stream);
+
 /* Reference-shaped primitives (the same pipeline stage by stage, as the reference runs it). */
 
 /* replaces: mapper/tile_mapper.py:74-84 tile_overlaps_kernel.  counts (v) int32. */
@@ -298,6 +303,73 @@ int gs_depth_split_fwd(int64_t pixels, int32_t channels, const float* image, con
 int gs_depth_split_bwd(int64_t pixels, int32_t channels, const float* depth, const float* alpha, float eps,
                        const float* grad_features, const float* grad_depth, const float* grad_depth_var,
                        float* grad_image, void* stream);
+
+/* --------------------------------------------------- one call per direction --
+ * replaces: renderer.py:134-231 render_gaussians as a whole -- project_to_image (:154-157), evaluate_sh_at / the
+ * feature gather (:160-166), map_to_tiles + rasterize_with_tiles (render_projected, :183-231), the depth / variance
+ * epilogue (:174-180) and the median-depth pass (:203-208) -- and its autograd backward.
+ *
+ * gs_frame_fwd and gs_frame_bwd enqueue the entry points above, in the order and with the arguments of the
+ * stage-by-stage composition (results are bit-identical), from ONE host call each, into ONE caller-provided workspace:
+ * gs_frame_layout gives the byte offset of every sub-buffer (-1 = not present for this frame) so that the caller can
+ * view them as tensors.  No allocation and no synchronisation inside.
+ *   GsFrame (host struct): the frame.  sh_degree -1 = plain (n, channels) features (use_sh=False).  k_capacity (>= 1):
+ *     how many (tile, splat) overlaps the workspace holds; the mapper clamps to it and raises the overflow flag
+ *     (counts word [6]), in which case the caller runs the frame again with more room.  max_tile_hint: expected
+ *     population of the fullest tile (sizes the per-tile sort launches; 0 = none; fuller tiles are still sorted).
+ *     prepare_backward: the forward also zero-fills the gradient rows gs_frame_bwd accumulates into (inside the
+ *     projection's compaction pass: no fill launch); without it gs_frame_bwd clears its own rows first.
+ *   workspace (gs_frame_layout().workspace_bytes): outputs and everything the backward reads.  `counts` is int32[8]:
+ *     [0] = V, [4] = K, [5] = fullest tile, [6] = overflow flag, [7] = heavy tiles.  Per-Gaussian buffers are sized
+ *     for n rows; V rows are live.  scratch: fwd_scratch_bytes / bwd_scratch_bytes, dead when the call's work has run.
+ *   counts_host (optional, pinned host int32[5]) as in gs_map_prepare: {K, fullest tile, overflow, heavy, V}.
+ *   counts_event (optional, a hipEvent_t): recorded on `stream` right behind the mapper's scan, i.e. when counts_host is
+ *     final -- the caller waits on it for V and K while the sort and the rasterizer are still running.
+ *   gs_frame_bwd: v, k = the counts read back; grad_image (H, W, C) and, with render_depth, grad_img_depth /
+ *     grad_img_var (H, W) -- any may be NULL (zero); attached_points (v, 7) / attached_depth (v): gradients the caller
+ *     attached to the projected splats / depths themselves (optional).  Outputs: dense parameter gradients
+ *     d_position (n,3), d_log_scaling (n,3), d_rotation (n,4), d_alpha_logit (n,1), d_feature (n,C[,D]);
+ *     d_T_camera_world (16) / d_projection (4) optional; d_camera_centre (3, optional, ZEROED BY THE CALLER) receives
+ *     the SH view direction's gradient with respect to the camera centre.  Not for sharded frames (their backward
+ *     exchanges partial gradients between the rasterizer and the per-Gaussian adjoints: run the stages).
+ */
+typedef struct GsFrame {
+  int64_t n;
+  int32_t channels, sh_degree;
+  int32_t width, height;          /* the FULL image, also under a shard */
+  double near_plane, far_plane;
+  int32_t render_depth, use_depth16, render_median_depth, prepare_backward;
+  int64_t k_capacity;
+  int32_t max_tile_hint;
+  int32_t has_shard;
+  GsRowShard shard;
+  GsRasterConfig cfg;
+} GsFrame;
+
+typedef struct GsFrameLayout {
+  int64_t workspace_bytes, fwd_scratch_bytes, bwd_scratch_bytes, stage_bytes;
+  /* workspace */
+  int64_t counts, camera_pos, points, depth, features, indexes, slot_of, tile_ranges, tile_order, overlap_to_point,
+      image, alpha, visibility, out_image, img_depth, img_var, median, grad_rows;
+  /* forward scratch */
+  int64_t s_ndc_depth, s_pairs, s_median_cover, s_stage;
+  /* backward scratch */
+  int64_t b_grad_image, b_camera, b_grad_rows;
+  int32_t num_features, grad_row_floats, tiles_x, tiles_y, local_height;
+} GsFrameLayout;
+
+int gs_frame_layout(const GsFrame* frame, GsFrameLayout* layout);
+int gs_frame_fwd(const GsFrame* frame, const float* position, const float* log_scaling, const float* rotation,
+                 const float* alpha_logit, const float* feature, const float* T_camera_world, const float* projection,
+                 void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, int32_t* counts_host,
+                 void* counts_event, void* stream);
+int gs_frame_bwd(const GsFrame* frame, const float* position, const float* log_scaling, const float* rotation,
+                 const float* alpha_logit, const float* feature, const float* T_camera_world, const float* projection,
+                 void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, int64_t v, int64_t k,
+                 const float* grad_image, const float* grad_img_depth, const float* grad_img_var,
+                 const float* attached_points, const float* attached_depth, float* d_position, float* d_log_scaling,
+                 float* d_rotation, float* d_alpha_logit, float* d_feature, float* d_T_camera_world,
+                 float* d_projection, float* d_camera_centre, void* stream);
 
 /* ------------------------------------------------------------------- Morton ordering --
  * replaces: misc/morton_sort.py:78-88 code_points64_kernel (Grid.morton_code64, :37-66).  points (n,3);

@@ -380,12 +380,12 @@ inline GridQuery grid_query(const float* g, int Wp, int Hp, int tile_size, float
     q.min_tx = q.min_ty = q.span_x = q.span_y = 0;
     return q;
   }
-  const float gscale = std::sqrt(2.0f * gs_det_logf(alpha / alpha_thr));  // grid_query.py:76
+  const float gscale = gs_det_sqrtf(2.0f * gs_det_logf(alpha / alpha_thr));  // grid_query.py:76
   const float sx = sgx * gscale, sy = sgy * gscale;
   const float a2x = -ay, a2y = ax;  // :79
   // ellipse_bounds(mean, axis1*sx, axis2*sy)  generic.py:235-237
   const float v1x = ax * sx, v1y = ay * sx, v2x = a2x * sy, v2y = a2y * sy;
-  const float ex = std::sqrt(v1x * v1x + v2x * v2x), ey = std::sqrt(v1y * v1y + v2y * v2y);
+  const float ex = gs_det_sqrtf(v1x * v1x + v2x * v2x), ey = gs_det_sqrtf(v1y * v1y + v2y * v2y);
   const float lox = mx - ex, loy = my - ey, hix = mx + ex, hiy = my + ey;
   q.ib00 = ax / sx; q.ib01 = ay / sx; q.ib10 = a2x / sy; q.ib11 = a2y / sy;  // :83
   // tile_ranges  grid_query.py:10-27

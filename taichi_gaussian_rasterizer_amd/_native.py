@@ -34,6 +34,26 @@ class GsRowShard(ctypes.Structure):
                 ("phase", c_int32)]
 
 
+class GsFrame(ctypes.Structure):
+    """include/gsplat_hip.h GsFrame: one render_gaussians frame for gs_frame_fwd / gs_frame_bwd"""
+    _fields_ = [("n", c_int64), ("channels", c_int32), ("sh_degree", c_int32), ("width", c_int32), ("height", c_int32),
+                ("near_plane", c_double), ("far_plane", c_double), ("render_depth", c_int32), ("use_depth16", c_int32),
+                ("render_median_depth", c_int32), ("prepare_backward", c_int32), ("k_capacity", c_int64),
+                ("max_tile_hint", c_int32), ("has_shard", c_int32), ("shard", GsRowShard), ("cfg", GsRasterConfig)]
+
+
+class GsFrameLayout(ctypes.Structure):
+    """include/gsplat_hip.h GsFrameLayout: byte offsets of the frame's sub-buffers (-1 = absent)"""
+    _OFFSETS = ("workspace_bytes", "fwd_scratch_bytes", "bwd_scratch_bytes", "stage_bytes",
+                "counts", "camera_pos", "points", "depth", "features", "indexes", "slot_of", "tile_ranges", "tile_order",
+                "overlap_to_point", "image", "alpha", "visibility", "out_image", "img_depth", "img_var", "median",
+                "grad_rows", "s_ndc_depth", "s_pairs", "s_median_cover", "s_stage", "b_grad_image", "b_camera",
+                "b_grad_rows")
+    _fields_ = [(name, c_int64) for name in _OFFSETS] + [
+        ("num_features", c_int32), ("grad_row_floats", c_int32), ("tiles_x", c_int32), ("tiles_y", c_int32),
+        ("local_height", c_int32)]
+
+
 # Developer tuning aids (tools/exp_*.py, the wave-region tests): passed per call inside GsRasterConfig; the
 # library itself reads no environment variable.  GS_RASTER_NB / GS_RASTER_HEAVY seed them at import.
 TUNING = {"wave_sub_blocks": int(os.environ.get("GS_RASTER_NB", "0") or 0),
@@ -41,6 +61,7 @@ TUNING = {"wave_sub_blocks": int(os.environ.get("GS_RASTER_NB", "0") or 0),
 
 
 _CFG = POINTER(GsRasterConfig)
+_FRAME = POINTER(GsFrame)
 _SHARD = POINTER(GsRowShard)
 _P = c_void_p
 _I32, _I64, _F64 = c_int32, c_int64, c_double
@@ -65,6 +86,7 @@ SIGNATURES = {
     "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _SHARD, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,
                                       _P, _I64, _P]),
+    "gs_selftest_detmath": (ctypes.c_int, [_I64, _P, _P, _P, _P]),
     "gs_tile_count": (ctypes.c_int, [_I64, _P, _I32, _I32, _CFG, _P, _P]),
     "gs_cumsum_scratch_bytes": (_I64, [_I64]),
     "gs_full_cumsum_i32": (ctypes.c_int, [_I64, _P, _P, _P, _I64, _P]),
@@ -87,6 +109,10 @@ SIGNATURES = {
     "gs_feature_gather_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, _I32, _P, _P]),
     "gs_depth_split_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P]),
     "gs_depth_split_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P, _P]),
+    "gs_frame_layout": (ctypes.c_int, [_FRAME, POINTER(GsFrameLayout)]),
+    "gs_frame_fwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P]),
+    "gs_frame_bwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _P,
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

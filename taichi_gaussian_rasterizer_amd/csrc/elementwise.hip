@@ -87,7 +87,28 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(int64_t v, int F, int c
   }
 }
 
+// gradients the caller attached to the projected splats / depths themselves, added to the rasterizer's gradient rows
+__global__ __launch_bounds__(256) void rows_add_kernel(int64_t v, int row_floats, float* rows, const float* add_points,
+                                                       const float* add_depth, int depth_col) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int64_t i = e >> 3;
+  if (i >= v) return;
+  const int c = int(e & 7);
+  if (c < 7) { if (add_points) rows[i * row_floats + c] += add_points[i * 7 + c]; }
+  else if (add_depth) rows[i * row_floats + depth_col] += add_depth[i];
+}
+
 }  // namespace
+
+int gs_rows_add(int64_t v, int32_t row_floats, float* rows, const float* add_points, const float* add_depth,
+                int32_t depth_col, void* stream) {
+  if (v == 0 || (!add_points && !add_depth)) return GS_OK;
+  GS_REQUIRE(rows, GS_ERR_INVALID_ARGUMENT, "gs_rows_add: rows is NULL");
+  hipLaunchKernelGGL(rows_add_kernel, dim3(unsigned(gs_div_up(v * 8, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), v, row_floats, rows, add_points, add_depth, depth_col);
+  GS_CHECK_LAUNCH("gs_rows_add");
+  return GS_OK;
+}
 
 extern "C" int gs_shard_pack_grads(int64_t v, int32_t num_features, int32_t colour_col0, const float* grad_rows,
                                    const float* features, float* colour_out, float* splat_out, void* stream) {

@@ -108,6 +108,17 @@ static inline int gs_make_shard(const GsRowShard* shard, int rows, GsShard* out)
 // staging work per splat.  Results do not depend on it.
 int gs_raster_sub_blocks(const GsRasterConfig* cfg, int64_t num_tiles, int backward);
 
+// library-internal entry points behind gs_frame_fwd / gs_frame_bwd (frame.cpp)
+int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling, const float* rotation,
+                      const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
+                      int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
+                      float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
+                      float* depth_features, int32_t depth_features_stride, float* camera_pos, void* scratch,
+                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, void* stream);
+// rows[i, 0..7) += add_points[i, 0..7) and rows[i, depth_col] += add_depth[i] for i < v (either may be NULL)
+int gs_rows_add(int64_t v, int32_t row_floats, float* rows, const float* add_points, const float* add_depth,
+                int32_t depth_col, void* stream);
+
 // ------------------------------------------------------------------ device helpers
 #ifdef __HIPCC__
 

@@ -2,7 +2,8 @@
 // (reference mapper/tile_mapper.py:74-196, taichi_lib/grid_query.py:10-91).
 //
 // COMPILED WITH -ffp-contract=off.  Every f32 operation of the grid query is a single correctly
-// rounded IEEE op in the same order as oracle/gsplat_oracle.cpp, and the logarithm is
+// rounded IEEE op in the same order as oracle/gsplat_oracle.cpp (the square roots through gs_det_sqrtf: hipcc's
+// __fsqrt_rn is the 1-ulp native instruction), and the logarithm is
 // gs_det_logf (include/gs_detmath.h), so the integer results -- which tiles a splat touches, the
 // sort keys, the order inside every tile -- are bit-identical to the CPU oracle.
 //
@@ -48,11 +49,11 @@ __device__ __forceinline__ GridQuery grid_query(const float* g, int Wp, int Hp, 
     q.min_tx = q.min_ty = q.span_x = q.span_y = 0;
     return q;
   }
-  const float gscale = __fsqrt_rn(2.0f * gs_det_logf(__fdiv_rn(alpha, alpha_thr)));
+  const float gscale = gs_det_sqrtf(2.0f * gs_det_logf(__fdiv_rn(alpha, alpha_thr)));
   const float sx = sgx * gscale, sy = sgy * gscale;
   const float a2x = -ay, a2y = ax;
   const float v1x = ax * sx, v1y = ay * sx, v2x = a2x * sy, v2y = a2y * sy;
-  const float ex = __fsqrt_rn(v1x * v1x + v2x * v2x), ey = __fsqrt_rn(v1y * v1y + v2y * v2y);
+  const float ex = gs_det_sqrtf(v1x * v1x + v2x * v2x), ey = gs_det_sqrtf(v1y * v1y + v2y * v2y);
   const float lox = mx - ex, loy = my - ey, hix = mx + ex, hiy = my + ey;
   q.ib00 = __fdiv_rn(ax, sx); q.ib01 = __fdiv_rn(ay, sx); q.ib10 = __fdiv_rn(a2x, sy); q.ib11 = __fdiv_rn(a2y, sy);
   const float ts = float(tile_size);
@@ -1142,6 +1143,24 @@ extern "C" int gs_segmented_sort_pairs(int64_t num_items, int32_t key_bytes, con
                        static_cast<int16_t*>(keys_out), values_out, static_cast<uint64_t*>(scratch));
   }
   GS_CHECK_LAUNCH("gs_segmented_sort_pairs");
+  return GS_OK;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void detmath_kernel(int64_t n, const float* x, float* sqrt_out, float* log_out) {
+  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (sqrt_out) sqrt_out[i] = gs_det_sqrtf(x[i]);
+  if (log_out) log_out[i] = gs_det_logf(x[i]);
+}
+}  // namespace
+
+extern "C" int gs_selftest_detmath(int64_t n, const float* x, float* sqrt_out, float* log_out, void* stream) {
+  if (n == 0) return GS_OK;
+  GS_REQUIRE(x, GS_ERR_INVALID_ARGUMENT, "gs_selftest_detmath: x is NULL");
+  hipLaunchKernelGGL(detmath_kernel, dim3(unsigned(gs_div_up(n, 256))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     n, x, sqrt_out, log_out);
+  GS_CHECK_LAUNCH("gs_selftest_detmath");
   return GS_OK;
 }
 

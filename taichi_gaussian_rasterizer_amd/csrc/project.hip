@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_row
 __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* st_rows, const int* block_offsets,
                                                       const int* block_counts, int num_blocks, float inv_far, float ndc_denom, float* points,
                                                       float* depth, float* ndc, int64_t* indexes, int* slot_of,
-                                                      int* num_visible, float* depth_feat, int depth_feat_stride) {
+                                                      int* num_visible, float* depth_feat, int depth_feat_stride,
+                                                      float4* zero_rows, int zero_row_v4) {
   __shared__ int s_cnt[4];
   __shared__ int s_before[4];
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -198,6 +199,10 @@ __global__ __launch_bounds__(256) void compact_kernel(int64_t n, const float4* s
       const float inv_d = __fdiv_rn(1.0f, r1.w);
       ndc[slot] = 1.0f - __fdiv_rn(inv_d - inv_far, ndc_denom);
       indexes[slot] = i;
+      // the frame's gradient rows (gs_raster_bwd accumulates into them with atomics): zero-filled here, by the pass
+      // that already streams the V compact rows, instead of by a fill launch in front of the backward
+      if (zero_rows)
+        for (int q = 0; q < zero_row_v4; ++q) zero_rows[int64_t(slot) * zero_row_v4 + q] = make_float4(0, 0, 0, 0);
     }
     slot_of[i] = slot;
   }
@@ -417,6 +422,19 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
                               int64_t* indexes, int32_t* slot_of, int32_t* num_visible, float* depth_features,
                               int32_t depth_features_stride, float* camera_pos, void* scratch,
                               int64_t scratch_bytes, void* stream) {
+  return gs_project_fwd_ex(n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
+                           near_plane, far_plane, cfg, points, depth, ndc_depth, indexes, slot_of, num_visible,
+                           depth_features, depth_features_stride, camera_pos, scratch, scratch_bytes, nullptr, 0, stream);
+}
+
+// gs_project_fwd + (library-internal, used by gs_frame_fwd) zero_rows: a (V, zero_row_floats) buffer, 16-byte aligned
+// rows, whose first V rows the compaction pass zero-fills
+int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling, const float* rotation,
+                      const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
+                      int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
+                      float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
+                      float* depth_features, int32_t depth_features_stride, float* camera_pos, void* scratch,
+                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, void* stream) {
   ProjArgs a;
   if (int rc = fill(a, n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
                     near_plane, far_plane, cfg))
@@ -447,7 +465,8 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
   if (!self_offsets)
     if (int rc = gs_full_cumsum_i32(nb, counts, offsets, scan_scratch, gs_cumsum_scratch_bytes(nb), s)) return rc;
   hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, s, n, st_rows, self_offsets ? nullptr : offsets, counts, nb, a.inv_far, a.ndc_denom,
-                     points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride);
+                     points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride,
+                     reinterpret_cast<float4*>(zero_rows), zero_row_floats / 4);
   GS_CHECK_LAUNCH("gs_project_fwd/compact");
   return GS_OK;
 }

@@ -86,9 +86,14 @@ struct BwdShape {
   static constexpr int ARENA_F = (REC_F + ACC_F) > OUT_F ? (REC_F + ACC_F) : OUT_F;
 };
 
+#ifndef GS_BWD_LDS_REDUCE
+#define GS_BWD_LDS_REDUCE 0  // 1: the first 8 of 9 values of the lean F = 3 reduction are transposed through LDS
+#endif
+constexpr int TR_STRIDE = 68;  // floats per value row of the transposition buffer (64 lanes + 4: b128 reads stay aligned)
+
 template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, int yout0, float* smem,
-                                                int* s_idx) {
+                                                int* s_idx, float* s_tr) {
   const int lane = threadIdx.x;
   constexpr bool FULL = MODE == 2, HEUR = MODE == 1;
   constexpr int NS = MODE == 2 ? 9 : MODE == 1 ? 8 : 6;  // sums per splat besides the F feature gradients
@@ -314,7 +319,34 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       if (any_grad) {
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
         // up owning value k stores it (one ds_write_b32 for all values of a chunk)
-        if (NACC <= 16) {
+        if (GS_BWD_LDS_REDUCE && NACC == 9) {
+          // Transposed through LDS instead of the register butterfly: every lane stores its 8 partial sums (row c =
+          // value c, column = lane), then lane (c = lane >> 3, s = lane & 7) adds columns 8 s .. 8 s + 7 of row c and
+          // three DPP adds fold the eight lanes of a value.  7 adds + 3 DPP against ~42 issue slots of swaps and DPP;
+          // the wave's own LDS accesses execute in order, so nothing but the compiler needs a fence.
+          float vals[9];
+#pragma unroll
+          for (int c = 0; c < 9; ++c) vals[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) s_tr[c * TR_STRIDE + lane] = vals[c];
+          float x = vals[8];
+          x = gs_dpp_add_full<0x128>(x);
+          x = gs_dpp_add_full<0x124>(x);
+          x = gs_dpp_add_full<0x122>(x);
+          x = gs_dpp_add_full<0x121>(x);
+          x = gs_dpp_add_full<0x142>(x);
+          x = gs_dpp_add_full<0x143>(x);
+          __syncthreads();
+          const float4* rowp = reinterpret_cast<const float4*>(s_tr + (lane >> 3) * TR_STRIDE + (lane & 7) * 8);
+          const float4 u0 = rowp[0], u1 = rowp[1];
+          float t = ((u0.x + u0.y) + (u0.z + u0.w)) + ((u1.x + u1.y) + (u1.z + u1.w));
+          t = gs_dpp_add_full<0xB1>(t);   // quad_perm:[1,0,3,2]
+          t = gs_dpp_add_full<0x4E>(t);   // quad_perm:[2,3,0,1]
+          t = gs_dpp_add_full<0x141>(t);  // row_half_mirror: the other quad of the 8-lane group
+          if ((lane & 7) == 0) s_acc[j][lane >> 3] = t;
+          if (lane == 60) s_acc[j][8] = x;
+          __syncthreads();
+        } else if (NACC <= 16) {
           float vals[NACC <= 16 ? NACC : 1];
 #pragma unroll
           for (int c = 0; c < NACC && c < 16; ++c) vals[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];
@@ -401,6 +433,12 @@ template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[BwdShape<FP, MODE>::ARENA_F];
   __shared__ int s_idx[64];
+#if GS_BWD_LDS_REDUCE
+  __shared__ __attribute__((aligned(16))) float s_tr_buf[8 * TR_STRIDE];
+  float* s_tr = s_tr_buf;
+#else
+  float* s_tr = nullptr;
+#endif
   const int per_tile = a.sub_x * a.sub_y;
   constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
   int tile, quad;
@@ -412,7 +450,7 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
       int x0, y0, yout0;
       tile_origin(a, tile, x0, y0, yout0);
       x0 += (b & 1) * 8; y0 += ((b >> 1) & 1) * 8; yout0 += ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx);
+      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx, s_tr);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -429,7 +467,7 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   tile_origin(a, tile, x0, y0, yout0);
   x0 += (quad % a.sub_x) * RW; y0 += (quad / a.sub_x) * RH; yout0 += (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx);
+  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx, s_tr);
 }
 
 template <int NB, int MODE>

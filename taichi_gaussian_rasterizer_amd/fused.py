@@ -25,6 +25,9 @@ from .data_types import RasterConfig
 from .spherical_harmonics import check_sh_degree
 
 _K_HINT = {}  # (n, w, h, tile_size, use_depth16) -> (max overlaps, max tile population) seen for that shape
+# True: gs_frame_fwd / gs_frame_bwd for every frame but the first of its shape; False: always the stages; "always":
+# the frame calls also for a first frame, after an untracked sizing pass (tests/conftest.py frame_path)
+FRAME_CALLS = True
 _PINNED = {}  # device index -> ring of pinned int32[8] host buffers for the asynchronous count read-back
 
 
@@ -207,8 +210,14 @@ class _FusedRender(torch.autograd.Function):
     @nv.on_tensor_device
     def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var,
                  _g_median=None):
+        return _backward_stages(ctx, ctx.saved_tensors, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 9
+
+
+def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_var):
+    """the frame's backward, one C-ABI entry point per stage; returns the seven input gradients"""
+    if True:
         (position, log_scaling, rotation, alpha_logit, feature, T, proj, points, feats, slot_of, indexes, cam_pos,
-         tile_ranges, o2p, image, alpha, img_depth, tile_order, counts) = ctx.saved_tensors
+         tile_ranges, o2p, image, alpha, img_depth, tile_order, counts) = saved
         m = ctx.meta
         lib = nv.lib()
         dev = position.device
@@ -326,8 +335,235 @@ class _FusedRender(torch.autograd.Function):
                 dY = torch.zeros((4, 4), dtype=torch.float64)
                 dY[:3, 3] = d_centre.cpu().double()
                 d_T = d_T + (-(Y.T @ dY @ Y.T)).to(device=dev, dtype=torch.float32)
-        return (d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj, None, None, None, None, None, None, None, None,
-                None)
+        return (d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# One C-ABI call per direction (include/gsplat_hip.h gs_frame_fwd / gs_frame_bwd): the same stages as _FusedRender
+# above, enqueued from a single host call into one workspace whose sub-buffers are carved by offset.  Used for every
+# frame whose overlap count has been seen before (the first frame of a shape has to read K back before the pair
+# buffers can be sized: that one runs _FusedRender, as does the re-run after a capacity overflow).
+_FRAMES = {}   # frame key -> (GsFrame, GsFrameLayout)
+_EVENTS = {}   # device index -> ring of (torch.cuda.Event, raw handle)
+_EMPTY = {}    # (device, shape) -> cached empty placeholder outputs
+
+
+class _Overflow(Exception):
+    pass
+
+
+def _frame_for(n, C, degree, w, full_h, depth_range, render_depth, use_depth16, render_median, prepare_backward,
+               k_cap, tile_hint, shard, config):
+    key = (n, C, degree, w, full_h, float(depth_range[0]), float(depth_range[1]), render_depth, use_depth16,
+           render_median, prepare_backward, k_cap, tile_hint, shard, config, nv.TUNING["wave_sub_blocks"],
+           nv.TUNING["no_heavy_split"])
+    hit = _FRAMES.get(key)
+    if hit is None:
+        frame = nv.GsFrame()
+        frame.n, frame.channels, frame.sh_degree, frame.width, frame.height = n, C, degree, w, full_h
+        frame.near_plane, frame.far_plane = float(depth_range[0]), float(depth_range[1])
+        frame.render_depth, frame.use_depth16 = int(render_depth), int(use_depth16)
+        frame.render_median_depth, frame.prepare_backward = int(render_median), int(prepare_backward)
+        frame.k_capacity, frame.max_tile_hint = int(k_cap), int(tile_hint)
+        frame.has_shard = 0 if shard is None else 1
+        if shard is not None:
+            frame.shard = nv.GsRowShard(int(shard.row_begin), int(shard.row_end), int(shard.band), int(shard.period),
+                                        int(shard.phase))
+        frame.cfg = nv.make_config(config)
+        layout = nv.GsFrameLayout()
+        nv.check(nv.lib().gs_frame_layout(ctypes.byref(frame), ctypes.byref(layout)), "gs_frame_layout")
+        if len(_FRAMES) > 256:
+            _FRAMES.clear()
+        hit = _FRAMES[key] = (frame, layout)
+    return hit
+
+
+def _counts_event(dev: torch.device):
+    ring = _EVENTS.get(dev.index)
+    if ring is None:
+        evs = []
+        for _ in range(4):
+            ev = torch.cuda.Event()
+            ev.record()  # creates the underlying hipEvent_t, whose handle the library records later
+            evs.append((ev, ctypes.c_void_p(ev.cuda_event)))
+        ring = _EVENTS[dev.index] = dict(evs=evs, at=0)
+    ring["at"] = (ring["at"] + 1) % len(ring["evs"])
+    return ring["evs"][ring["at"]]
+
+
+def _empty(dev, shape):
+    key = (dev, shape)
+    t = _EMPTY.get(key)
+    if t is None:
+        t = _EMPTY[key] = torch.empty(shape, dtype=torch.float32, device=dev)
+    return t
+
+
+class _FrameRender(torch.autograd.Function):
+    @staticmethod
+    @nv.on_tensor_device
+    def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
+                image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool,
+                render_median: bool, shard, group, holder, key, k_cap: int, tile_hint: int):
+        nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
+                          what="render_gaussians")
+        lib = nv.lib()
+        dev = position.device
+        n = position.shape[0]
+        w, full_h = int(image_size[0]), int(image_size[1])
+        C = feature.shape[1]
+        degree = check_sh_degree(feature) if feature.dim() == 3 else -1
+        needs_grad = any(ctx.needs_input_grad[:7])
+        # a sharded frame's backward runs stage by stage (the exchange sits in its middle) and clears its own rows
+        prepare_backward = needs_grad and shard is None
+        frame, L = _frame_for(n, C, degree, w, full_h, depth_range, render_depth, use_depth16, render_median,
+                              prepare_backward, k_cap, tile_hint, shard, config)
+        T = T_camera_world.contiguous()
+        proj = projection.contiguous()
+        ws = torch.empty((L.workspace_bytes,), dtype=torch.uint8, device=dev)
+        scratch = torch.empty((L.fwd_scratch_bytes,), dtype=torch.uint8, device=dev)
+        host_counts = _pinned_counts(dev)
+        ready, ready_handle = _counts_event(dev)
+        nv.check(lib.gs_frame_fwd(ctypes.byref(frame), nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation),
+                                  nv.ptr(alpha_logit), nv.ptr(feature), nv.ptr(T), nv.ptr(proj), nv.ptr(ws),
+                                  L.workspace_bytes, nv.ptr(scratch), L.fwd_scratch_bytes, nv.ptr(host_counts),
+                                  ready_handle, nv.stream()), "gs_frame_fwd")
+        ready.synchronize()  # waits for the mapper's scan only, not for the rasterizer
+        host = host_counts.tolist()
+        K, max_tile, overflow, V = host[0], host[1], host[2], host[4]
+        hint = _K_HINT.get(key)
+        _K_HINT[key] = (max(K, hint[0]) if hint else K, max(max_tile, hint[1]) if hint else max_tile)
+        if overflow:  # more overlaps than the hint allowed for: the caller runs the frame again with exact sizes
+            raise _Overflow()
+
+        F, h = L.num_features, L.local_height
+        f32 = ws.view(torch.float32)
+
+        def view(off, shape, base=f32, esize=4):
+            strides, acc = [], 1
+            for s_ in reversed(shape):
+                strides.append(acc)
+                acc *= s_
+            return base.as_strided(shape, tuple(reversed(strides)), off // esize).detach()
+
+        image = view(L.image, (h, w, F))
+        alpha = view(L.alpha, (h, w))
+        points_v = view(L.points, (V, 7))
+        depth_v = view(L.depth, (V, 1))
+        indexes_v = view(L.indexes, (V,), ws.view(torch.int64), 8)
+        empty = _empty(dev, (0,))
+        vis_out = view(L.visibility, (V,)) if config.compute_visibility else empty
+        heur = torch.zeros((V, 2), dtype=torch.float32, device=dev) if config.compute_point_heuristic \
+            else _empty(dev, (0, 2))
+        out_image = image
+        img_depth = img_var = empty
+        if render_depth:
+            out_image = view(L.out_image, (h, w, C))
+            img_depth, img_var = view(L.img_depth, (h, w)), view(L.img_var, (h, w))
+        median = empty
+        if render_median:
+            median = view(L.median, (h, w))
+
+        ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, full_h=full_h, F=F, C=C, col0=F - C, degree=degree, config=config,
+                        render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]))
+        ctx.frame, ctx.layout = frame, L
+        ctx.heur = heur
+        ctx.holder = holder
+        ctx.rows_clean = prepare_backward
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(position, log_scaling, rotation, alpha_logit, feature, T, proj, ws)
+        ctx.mark_non_differentiable(alpha, indexes_v, vis_out, heur, median)
+        if not render_depth:
+            ctx.mark_non_differentiable(img_depth, img_var)
+        return out_image, alpha, points_v, depth_v, indexes_v, vis_out, heur, img_depth, img_var, median
+
+    @staticmethod
+    @nv.on_tensor_device
+    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var,
+                 _g_median=None):
+        position, log_scaling, rotation, alpha_logit, feature, T, proj, ws = ctx.saved_tensors
+        m, frame, L = ctx.meta, ctx.frame, ctx.layout
+        if m["shard"] is not None:
+            # a sharded frame exchanges its partial gradients between the rasterizer's backward and the per-Gaussian
+            # adjoints: stage by stage, on views of the workspace
+            f32_, i32_ = ws.view(torch.float32), ws.view(torch.int32)
+
+            def vw(base, off, shape, esize=4):
+                strides, acc = [], 1
+                for s_ in reversed(shape):
+                    strides.append(acc)
+                    acc *= s_
+                return base.as_strided(shape, tuple(reversed(strides)), off // esize)
+
+            n_, F_, h_, w_ = m["n"], m["F"], m["h"], m["w"]
+            T_tiles = max(L.tiles_x * L.tiles_y, 0)
+            saved = (position, log_scaling, rotation, alpha_logit, feature, T, proj,
+                     vw(f32_, L.points, (n_, 7)), vw(f32_, L.features, (n_, F_)), vw(i32_, L.slot_of, (n_,)),
+                     vw(ws.view(torch.int64), L.indexes, (n_,), 8), vw(f32_, L.camera_pos, (3,)),
+                     vw(i32_, L.tile_ranges, (T_tiles, 2)), vw(i32_, L.overlap_to_point, (frame.k_capacity,)),
+                     vw(f32_, L.image, (h_, w_, F_)), vw(f32_, L.alpha, (h_, w_)),
+                     vw(f32_, L.img_depth, (h_, w_)) if m["render_depth"] else _empty(position.device, (0,)),
+                     vw(i32_, L.tile_order, (T_tiles,)), vw(i32_, L.counts, (8,)))
+            return _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 12
+        lib = nv.lib()
+        dev = position.device
+        n, V, K, F = m["n"], m["V"], m["K"], m["F"]
+        config = m["config"]
+        RS = L.grad_row_floats
+        f32 = ws.view(torch.float32)
+        scratch = torch.empty((L.bwd_scratch_bytes,), dtype=torch.uint8, device=dev)
+        rows_off = L.grad_rows if L.grad_rows >= 0 else None
+        rows = (f32.as_strided((max(V, 1), RS), (RS, 1), L.grad_rows // 4) if rows_off is not None
+                else scratch.view(torch.float32).as_strided((max(V, 1), RS), (RS, 1), L.b_grad_rows // 4))
+        if rows_off is not None and not ctx.rows_clean:
+            rows.zero_()  # a second backward through the same frame (retain_graph): the rows hold the first one's sums
+        ctx.rows_clean = False
+        gi = gd_ = gv_ = None
+        if g_image is not None:
+            gi = g_image.contiguous()
+        if m["render_depth"]:
+            gd_ = g_img_depth.contiguous() if g_img_depth is not None else None
+            gv_ = g_img_var.contiguous() if g_img_var is not None else None
+        att_p = g_points.contiguous() if (g_points is not None and V > 0) else None
+        att_d = g_depth.contiguous() if (g_depth is not None and V > 0) else None
+        nv.require_device(gi, gd_, gv_, att_p, att_d, what="render_gaussians backward")
+        need_T, need_proj = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
+        # one allocation for the five parameter gradients
+        sizes = (position.numel(), log_scaling.numel(), rotation.numel(), alpha_logit.numel(), feature.numel())
+        flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+        outs, at = [], 0
+        for t, sz in zip((position, log_scaling, rotation, alpha_logit, feature), sizes):
+            outs.append(flat.as_strided(t.shape, t.stride(), at))
+            at += sz
+        d_pos, d_ls, d_rot, d_al, d_feature = outs
+        d_T = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_T else None
+        d_proj = torch.empty((4,), dtype=torch.float32, device=dev) if need_proj else None
+        d_centre = None
+        if m["degree"] >= 1 and need_T:
+            d_centre = torch.zeros((3,), dtype=torch.float32, device=dev)
+        nv.check(lib.gs_frame_bwd(ctypes.byref(frame), nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation),
+                                  nv.ptr(alpha_logit), nv.ptr(feature), nv.ptr(T), nv.ptr(proj), nv.ptr(ws),
+                                  L.workspace_bytes, nv.ptr(scratch), L.bwd_scratch_bytes, V, K, nv.ptr(gi),
+                                  nv.ptr(gd_), nv.ptr(gv_), nv.ptr(att_p), nv.ptr(att_d), nv.ptr(d_pos), nv.ptr(d_ls),
+                                  nv.ptr(d_rot), nv.ptr(d_al), nv.ptr(d_feature), nv.ptr(d_T), nv.ptr(d_proj),
+                                  nv.ptr(d_centre), nv.stream()), "gs_frame_bwd")
+        if config.compute_point_heuristic and V > 0:
+            ctx.heur.copy_(rows[:V, 7 + F:9 + F])
+        # publish the rasterizer's part of dL/d(gaussians2d) (see _FusedRender.backward)
+        out = ctx.holder.get("gaussians2d") if ctx.holder else None
+        out = out() if out is not None else None
+        if out is not None and out.retains_grad:
+            part = rows[:V, :7].clone() if V > 0 else rows.new_zeros((0, 7))
+            if att_p is not None:
+                part -= att_p  # the rows hold the attached gradient as well; the retain_grad hook has stored that part
+            out.grad = part if out.grad is None else out.grad + part
+        if d_centre is not None:  # Y = T^-1, dL/dT = -Y^T (dL/dY) Y^T with dL/dY zero except the centre column
+            with torch.no_grad():
+                Y = torch.linalg.inv(T.detach().cpu().double())
+                dY = torch.zeros((4, 4), dtype=torch.float64)
+                dY[:3, 3] = d_centre.cpu().double()
+                d_T = d_T + (-(Y.T @ dY @ Y.T)).to(device=dev, dtype=torch.float32)
+        return (d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj) + (None,) * 12
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
@@ -351,11 +587,30 @@ def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: b
 
     from .renderer import Rendering
     holder = {}
-    image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var, median = _FusedRender.apply(
-        gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
-        gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
-        camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
-        use_depth16, render_median_depth, shard, group, holder)
+    args = (gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
+            gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
+            camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
+            use_depth16, render_median_depth, shard, group, holder)
+    size = camera_params.image_size
+    key = (args[0].shape[0], int(size[0]), int(size[1]), shard, config.tile_size, bool(use_depth16))
+    hint = _K_HINT.get(key)
+    outs = None
+    if hint is None and FRAME_CALLS == "always":  # tests: size the frame by an untracked staged pass first
+        with torch.no_grad():
+            _FusedRender.apply(*args)
+        hint = _K_HINT.get(key)
+    if hint is not None and FRAME_CALLS:
+        # one C-ABI call per direction; capacities rounded up to a few classes so that the cached frame descriptors
+        # and workspace layouts are reused from frame to frame
+        k_cap = -(-(int(hint[0] * 1.25) + 4096) // 65536) * 65536
+        tile_hint = next((c for c in (256, 512, 1024, 2048) if hint[1] <= c), 4096)
+        try:
+            outs = _FrameRender.apply(*args, key, k_cap, tile_hint)
+        except _Overflow:
+            outs = None  # more overlaps than the hint allowed for (now updated): run the stages with exact sizes
+    if outs is None:
+        outs = _FusedRender.apply(*args)
+    image, alpha, g2d, depths, indexes, vis, heur, img_depth, img_var, median = outs
     holder["gaussians2d"] = weakref.ref(g2d)
     indexes._gs_unique = True
     if not render_depth:

@@ -26,6 +26,12 @@ FLIP_MARGIN = 5e-6
 # projected mean and axes (~1e-4 px at 2048 px, relative 6e-8 of coordinates up to 2e3), which moves alpha by
 # |d ln alpha / dx| * 1e-4 = (r / sigma^2) * 1e-4 <= ~1e-3 relative for the sub-pixel sigmas of the test scenes
 E2E_FLIP_MARGIN = 2e-3
+# the antialiased pdf (taichi_lib/generic.py:341-357) is a product of two DIFFERENCES of sigmoids, S(a) - S(b): each
+# sigmoid carries ~6e-8 of absolute rounding while the difference itself is ~1e-2 ... 1e-3 where alpha sits at the
+# threshold in a splat's tail, and the HIP forward evaluates the difference in the cancellation-free form
+# (e_b - e_a) / ((1 + e_a)(1 + e_b)) where the oracle subtracts literally: the two alphas agree to ~1e-4 relative there
+# (measured on MI355X: out-of-tolerance pixels of the antialias tests have margins up to 5.6e-5)
+AA_FLIP_MARGIN = 2e-4
 MAX_FLIPS_PER_PIXEL = 3
 
 

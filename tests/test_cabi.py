@@ -101,3 +101,58 @@ def test_shard_only_entry_points_validate_on_the_host():
     assert lib.gs_shard_pack_grads(10, 3, 3, None, None, None, None, None) == -1     # colours must start inside the row
     assert lib.gs_shard_pack_grads(10, 5, 2, None, None, None, None, None) == -1 and b"NULL" in lib.gs_last_error()
     assert lib.gs_shard_pack_grads(0, 5, 2, None, None, None, None, None) == 0
+
+
+def test_frame_layout_is_computed_on_the_host():
+    """gs_frame_layout (the workspace map of gs_frame_fwd / gs_frame_bwd) is host-only: sub-buffers are 256-byte
+    aligned, disjoint and inside the workspace; optional buffers are -1 unless the frame asks for them; the struct
+    layouts seen through ctypes are the header's; bad frames are refused before anything is launched"""
+    lib = _native.lib()
+    cfg = _native.GsRasterConfig(tile_size=16, alpha_threshold=1 / 255., forward_cut=2.0 ** -20)
+    assert ctypes.sizeof(_native.GsFrame) == 152 and ctypes.sizeof(_native.GsFrameLayout) == 29 * 8 + 5 * 4 + 4
+
+    def frame(**kw):
+        f = _native.GsFrame(n=1000, channels=3, sh_degree=3, width=100, height=70, near_plane=0.1, far_plane=100.0,
+                            k_capacity=5000, cfg=cfg)
+        for k, v in kw.items():
+            setattr(f, k, v)
+        return f
+
+    lay = _native.GsFrameLayout()
+    assert lib.gs_frame_layout(ctypes.byref(frame()), ctypes.byref(lay)) == 0
+    assert (lay.num_features, lay.grad_row_floats, lay.tiles_x, lay.tiles_y, lay.local_height) == (3, 16, 7, 5, 70)
+    ws = ["counts", "camera_pos", "points", "depth", "features", "indexes", "slot_of", "tile_ranges", "tile_order",
+          "overlap_to_point", "image", "alpha"]
+    offs = [getattr(lay, k) for k in ws]
+    assert offs == sorted(offs) and offs[0] == 0 and all(o % 256 == 0 for o in offs)
+    assert lay.alpha + 100 * 70 * 4 <= lay.workspace_bytes
+    assert lay.points - lay.camera_pos >= 12 and lay.depth - lay.points >= 1000 * 28
+    for k in ("visibility", "out_image", "img_depth", "img_var", "median", "grad_rows", "s_median_cover", "b_grad_image"):
+        assert getattr(lay, k) == -1, k
+    assert lay.b_grad_rows >= 0 and lay.bwd_scratch_bytes >= 1000 * 64
+    assert lay.stage_bytes >= max(lib.gs_project_scratch_bytes(1000), lib.gs_map_scratch_bytes(1000, 35))
+
+    full = frame(render_depth=1, render_median_depth=1, prepare_backward=1)
+    full.cfg.compute_visibility = 1
+    assert lib.gs_frame_layout(ctypes.byref(full), ctypes.byref(lay)) == 0
+    assert lay.num_features == 5 and min(lay.visibility, lay.out_image, lay.img_depth, lay.img_var, lay.median,
+                                         lay.grad_rows, lay.s_median_cover) > 0 and lay.b_grad_image >= 0
+    assert lay.b_grad_rows == -1 and lay.grad_rows + 1000 * 64 <= lay.workspace_bytes
+
+    # a shard: the images hold the owned pixel rows only (tile rows 1-2 of 5, 32 pixel rows; the last tile row is cut)
+    sh = frame(has_shard=1, shard=_native.GsRowShard(1, 3, 5, 1, 0))
+    assert lib.gs_frame_layout(ctypes.byref(sh), ctypes.byref(lay)) == 0
+    assert (lay.tiles_y, lay.local_height) == (2, 32)
+    sh = frame(has_shard=1, shard=_native.GsRowShard(3, 5, 5, 1, 0))
+    assert lib.gs_frame_layout(ctypes.byref(sh), ctypes.byref(lay)) == 0 and lay.local_height == 70 - 48
+
+    assert lib.gs_frame_layout(ctypes.byref(frame(k_capacity=0)), ctypes.byref(lay)) == -1
+    assert lib.gs_frame_layout(ctypes.byref(frame(sh_degree=4)), ctypes.byref(lay)) == -2
+    assert lib.gs_frame_layout(ctypes.byref(frame(channels=9)), ctypes.byref(lay)) == -2 and b"channels" in lib.gs_last_error()
+    assert lib.gs_frame_layout(None, ctypes.byref(lay)) == -1
+    # the calls themselves check the buffers before any launch
+    f = frame()
+    rc = lib.gs_frame_fwd(ctypes.byref(f), None, None, None, None, None, None, None, None, 0, None, 0, None, None, None)
+    assert rc == -4 and b"workspace" in lib.gs_last_error()
+    rc = lib.gs_frame_bwd(ctypes.byref(sh), *([None] * 7), None, 0, None, 0, 0, 0, *([None] * 13), None)
+    assert rc == -2 and b"sharded" in lib.gs_last_error()

@@ -167,7 +167,7 @@ def test_eight_way_shard_at_c5_image_size(n, interleave):
         pu.assert_rows_close(sums[k], v.grad, f"summed partial grad rows {k}", tol=1e-3, frac=0.999)
 
 
-def test_viewspace_gradient_on_the_fused_frame():
+def test_viewspace_gradient_on_the_fused_frame(frame_path):
     """`gaussians2d.retain_grad()` + `viewspace_gradient` (reference renderer.py:234-239: the classic densification
     signal) on the default, fused path equals the composed operators' value"""
     from taichi_gaussian_rasterizer_amd.renderer import render_projected, viewspace_gradient
@@ -197,7 +197,7 @@ def test_viewspace_gradient_on_the_fused_frame():
         pu.assert_grad_close(v.grad, getattr(gc, k).grad, f"grad {k}", tol=1e-4)
 
 
-def test_gaussians2d_grad_accumulates_over_backward_passes():
+def test_gaussians2d_grad_accumulates_over_backward_passes(frame_path):
     """two losses backpropagated one after the other through the same Rendering, one of them attached to the projected
     splats themselves: `gaussians2d.grad` ends up as the SUM, as on the reference's composed graph (where the tensor is
     an ordinary non-leaf with retain_grad); an empty view publishes a (0, 7) gradient instead of none"""
