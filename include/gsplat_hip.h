@@ -164,6 +164,18 @@ int gs_sh_fwd_shard(int64_t v, const int32_t* v_dev, int32_t channels, int32_t d
  * gradient of clamped channels before the sum -- required with gs_sh_fwd_shard, whose other rows are 0.5. */
 int gs_shard_pack_grads(int64_t v, int32_t num_features, int32_t colour_col0, const float* grad_rows,
                         const float* features, float* colour_out, float* splat_out, void* stream);
+/* Sharded frame, sparse exchange: a rank's partial gradients cover the splats that can reach its rows only (7/8 of
+ * the rows an 8-rank all-reduce sums are zeros on every rank).  gs_shard_pack_sparse writes one entry of 8 + F words
+ * per touched splat: [row id (int32 bits), d splat (7), d features (F)] with the clamp mask of gs_shard_pack_grads
+ * applied (features (v,F) optional); `touched` (m int32 rows of the gradient-row buffer) is the mapper's list
+ * (gs_map_touched_offset) or any list of distinct rows.  gs_shard_add_sparse adds m entries into the two packed
+ * arrays gs_shard_pack_grads would have filled, splat_out (v, 7 + colour_col0) and colour_out (v, F - colour_col0):
+ * plain read-modify-write, the rows of ONE call are distinct, so calling it once per source rank in rank order
+ * gives every rank the same sums bit for bit. */
+int gs_shard_pack_sparse(int64_t m, const int32_t* touched, int32_t num_features, int32_t colour_col0,
+                         const float* grad_rows, const float* features, float* entries, void* stream);
+int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_features, int32_t colour_col0, int64_t v,
+                        float* colour_out, float* splat_out, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,
@@ -191,15 +203,20 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  * gs_map_finish means "not read back": its magnitude is only a hint for sizing the per-tile sort
  * (0 = no hint); fuller tiles are still sorted.  tile_order (optional, T int32) receives the tiles by
  * descending population: a launch order for gs_raster_fwd / gs_raster_bwd (heaviest tiles first).
- * counts_host (optional): device-accessible pinned HOST memory, int32[5]; the scan kernel stores the four
- * counts_out words and then *v_dev (0 without v_dev) there as well, so a caller that has to size buffers from K
- * waits for an event recorded behind gs_map_prepare and reads them -- no device-to-host copy launch.
+ * counts_host (optional): device-accessible pinned HOST memory, int32[6]; the scan kernel stores the four
+ * counts_out words, then *v_dev (0 without v_dev) and then M, the number of "touched" Gaussians (those whose
+ * candidate tile span reaches an owned tile row: the whole list the mapper works on), there as well, so a caller that
+ * has to size buffers from K waits for an event recorded behind gs_map_prepare and reads them -- no device-to-host
+ * copy launch.  The touched list itself -- M int32 rows of `points`, grouped by screen region -- is left in `scratch` at
+ * byte offset gs_map_touched_offset(v, num_tiles): a sharded frame exchanges the gradient rows of exactly these
+ * splats (gs_shard_pack_sparse).
  * shard (optional, host pointer, read during the call): only the owned tile rows are mapped; num_tiles in
  * gs_map_scratch_bytes and the T of tile_ranges / tile_order are then the LOCAL tile count, sorted_keys carry local
  * tile ids.  Tile decisions are computed in full-image coordinates: the tiles of a shard get exactly the lists the
  * unsharded call gives them.
  */
 int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
+int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
                    int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,
@@ -344,6 +361,9 @@ typedef struct GsFrame {
   int32_t has_shard;
   GsRowShard shard;
   GsRasterConfig cfg;
+  /* render_depth: cfg.forward_cut for the rasterizer call that blends [z, z^2, features] -- the caller divides its
+   * forward_cut by far^2 (GsRasterConfig.forward_cut above); the mapper and the median-depth pass use cfg as it is */
+  float depth_forward_cut;
 } GsFrame;
 
 typedef struct GsFrameLayout {

@@ -39,7 +39,8 @@ class GsFrame(ctypes.Structure):
     _fields_ = [("n", c_int64), ("channels", c_int32), ("sh_degree", c_int32), ("width", c_int32), ("height", c_int32),
                 ("near_plane", c_double), ("far_plane", c_double), ("render_depth", c_int32), ("use_depth16", c_int32),
                 ("render_median_depth", c_int32), ("prepare_backward", c_int32), ("k_capacity", c_int64),
-                ("max_tile_hint", c_int32), ("has_shard", c_int32), ("shard", GsRowShard), ("cfg", GsRasterConfig)]
+                ("max_tile_hint", c_int32), ("has_shard", c_int32), ("shard", GsRowShard), ("cfg", GsRasterConfig),
+                ("depth_forward_cut", c_float)]
 
 
 class GsFrameLayout(ctypes.Structure):
@@ -83,6 +84,9 @@ SIGNATURES = {
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
                                   _P]),
     "gs_map_scratch_bytes": (_I64, [_I64, _I64]),
+    "gs_map_touched_offset": (_I64, [_I64, _I64]),
+    "gs_shard_pack_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P]),
+    "gs_shard_add_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _I64, _P, _P, _P]),
     "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _SHARD, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,
                                       _P, _I64, _P]),

@@ -87,6 +87,42 @@ __global__ __launch_bounds__(256) void shard_pack_kernel(int64_t v, int F, int c
   }
 }
 
+// Sparse exchange of a sharded frame (include/gsplat_hip.h): entry e = [row id, 7 + F gradient words] of touched[e]
+__global__ __launch_bounds__(256) void shard_pack_sparse_kernel(int64_t m, const int* touched, int F, int col0,
+                                                                const float* rows, int row_floats,
+                                                                const float* features, float* entries) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int width = 8 + F;
+  const int64_t i = e / width;
+  if (i >= m) return;
+  const int c = int(e - i * width);
+  const int row = touched[i];
+  if (c == 0) { entries[e] = __int_as_float(row); return; }
+  float g = rows[int64_t(row) * row_floats + (c - 1)];
+  const int k = c - 8;  // feature column
+  if (k >= col0 && features != nullptr) {
+    const float o = features[int64_t(row) * F + k];
+    if (!(o > 0.0f && o < 1.0f)) g = 0.0f;
+  }
+  entries[e] = g;
+}
+
+__global__ __launch_bounds__(256) void shard_add_sparse_kernel(int64_t m, const float* entries, int F, int col0,
+                                                               int64_t v, float* colour, float* splat) {
+  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int width = 8 + F;
+  const int64_t i = e / width;
+  if (i >= m) return;
+  const int c = int(e - i * width);
+  if (c == 0) return;
+  const int64_t row = __float_as_int(entries[i * width]);
+  if (row < 0 || row >= v) return;  // padding of a fixed-size exchange buffer
+  const float g = entries[e];
+  const int k = c - 1;
+  if (k < 7 + col0) splat[row * (7 + col0) + k] += g;
+  else colour[row * (F - col0) + (k - 7 - col0)] += g;
+}
+
 // gradients the caller attached to the projected splats / depths themselves, added to the rasterizer's gradient rows
 __global__ __launch_bounds__(256) void rows_add_kernel(int64_t v, int row_floats, float* rows, const float* add_points,
                                                        const float* add_depth, int depth_col) {
@@ -99,6 +135,35 @@ __global__ __launch_bounds__(256) void rows_add_kernel(int64_t v, int row_floats
 }
 
 }  // namespace
+
+extern "C" int gs_shard_pack_sparse(int64_t m, const int32_t* touched, int32_t num_features, int32_t colour_col0,
+                                    const float* grad_rows, const float* features, float* entries, void* stream) {
+  GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES && colour_col0 >= 0 && colour_col0 < num_features,
+             GS_ERR_INVALID_ARGUMENT, "gs_shard_pack_sparse: %d features, colours from column %d", num_features,
+             colour_col0);
+  if (m == 0) return GS_OK;
+  GS_REQUIRE(touched && grad_rows && entries, GS_ERR_INVALID_ARGUMENT, "gs_shard_pack_sparse: NULL buffer");
+  const int64_t total = m * (8 + num_features);
+  hipLaunchKernelGGL(shard_pack_sparse_kernel, dim3(unsigned(gs_div_up(total, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), m, touched, num_features, colour_col0, grad_rows,
+                     gs_grad_row_floats(num_features), features, entries);
+  GS_CHECK_LAUNCH("gs_shard_pack_sparse");
+  return GS_OK;
+}
+
+extern "C" int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_features, int32_t colour_col0,
+                                   int64_t v, float* colour_out, float* splat_out, void* stream) {
+  GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES && colour_col0 >= 0 && colour_col0 < num_features,
+             GS_ERR_INVALID_ARGUMENT, "gs_shard_add_sparse: %d features, colours from column %d", num_features,
+             colour_col0);
+  if (m == 0 || v == 0) return GS_OK;
+  GS_REQUIRE(entries && colour_out && splat_out, GS_ERR_INVALID_ARGUMENT, "gs_shard_add_sparse: NULL buffer");
+  const int64_t total = m * (8 + num_features);
+  hipLaunchKernelGGL(shard_add_sparse_kernel, dim3(unsigned(gs_div_up(total, 256))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), m, entries, num_features, colour_col0, v, colour_out, splat_out);
+  GS_CHECK_LAUNCH("gs_shard_add_sparse");
+  return GS_OK;
+}
 
 int gs_rows_add(int64_t v, int32_t row_floats, float* rows, const float* add_points, const float* add_depth,
                 int32_t depth_col, void* stream) {

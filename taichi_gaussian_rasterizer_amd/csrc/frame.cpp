@@ -140,10 +140,7 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   const GsRasterConfig* cfg = &f->cfg;
   // what the forward's early stop may drop is bounded by forward_cut * max|feature|: z^2 reaches far^2
   GsRasterConfig rcfg = f->cfg;
-  if (f->render_depth) {
-    const double far2 = f->far_plane * f->far_plane;
-    rcfg.forward_cut = float(double(f->cfg.forward_cut) / (far2 > 1.0 ? far2 : 1.0));
-  }
+  if (f->render_depth) rcfg.forward_cut = f->depth_forward_cut;
   int32_t* counts = at<int32_t>(workspace, L.counts);
   float* cam_pos = at<float>(workspace, L.camera_pos);
   float* points = at<float>(workspace, L.points);
@@ -186,7 +183,8 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     if (hipMemsetAsync(counts + 4, 0, 16, s) != hipSuccess) { gs_set_error("gs_frame_fwd: memset failed"); return GS_ERR_LAUNCH; }
     if (counts_host) {
       if (hipMemcpyAsync(counts_host, counts + 4, 16, hipMemcpyDeviceToHost, s) != hipSuccess ||
-          hipMemcpyAsync(counts_host + 4, counts, 4, hipMemcpyDeviceToHost, s) != hipSuccess) {
+          hipMemcpyAsync(counts_host + 4, counts, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+          hipMemcpyAsync(counts_host + 5, counts + 5, 4, hipMemcpyDeviceToHost, s) != hipSuccess) {
         gs_set_error("gs_frame_fwd: count read-back failed");
         return GS_ERR_LAUNCH;
       }

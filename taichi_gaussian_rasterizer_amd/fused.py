@@ -49,7 +49,8 @@ class _FusedRender(torch.autograd.Function):
     @nv.on_tensor_device
     def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                 image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                render_median: bool = False, shard=None, group=None, holder=None):
+                render_median: bool = False, shard=None, group=None, holder=None, exchange: str = "dense",
+                grad_mode: str = "replicated", owned_range=None):
         nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                           what="render_gaussians")
         lib = nv.lib()
@@ -123,6 +124,7 @@ class _FusedRender(torch.autograd.Function):
             counts[4:8] = 0
             host_counts[:4].copy_(counts[4:8], non_blocking=True)
             host_counts[4:5].copy_(counts[0:1], non_blocking=True)
+            host_counts[5:6].copy_(counts[5:6], non_blocking=True)  # touched splats: none
             ready.record()
             return (torch.empty((0,), dtype=torch.int32, device=dev), torch.empty((0, w, F), **f32),
                     torch.empty((0, w), **f32), torch.zeros((n,), **f32) if want_vis else None)
@@ -194,7 +196,11 @@ class _FusedRender(torch.autograd.Function):
         heur = torch.zeros((V, 2), **f32) if config.compute_point_heuristic else torch.empty((0, 2), **f32)
 
         ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, full_h=full_h, F=F, C=C, col0=col0, degree=degree, config=config,
-                        render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]))
+                        render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]),
+                        exchange=exchange, grad_mode=grad_mode, owned_range=owned_range)
+        if shard is not None and exchange == "sparse":
+            _start_sparse_exchange(ctx.meta, n, num_tiles, host[5] if num_tiles > 0 else 0, indexes, mscratch, 0)
+        ctx.camera_grads = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])
         ctx.heur = heur
         ctx.holder = holder
         # outputs nobody differentiates through (projected splats, depths) must not cost zero-filled gradients
@@ -210,7 +216,34 @@ class _FusedRender(torch.autograd.Function):
     @nv.on_tensor_device
     def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var,
                  _g_median=None):
-        return _backward_stages(ctx, ctx.saved_tensors, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 9
+        return _backward_stages(ctx, ctx.saved_tensors, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 12
+
+
+def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, scratch_offset):
+    """Bookkeeping of a sharded frame's sparse exchange, done during the FORWARD: keep the mapper's list of the splats
+    that can reach this rank's rows (M int32 rows, left in the mapper scratch) and start the all-gather of the list
+    lengths (grad_mode "sharded": of the per-owner counts, the list sorted by Gaussian index so that the entries of one
+    owner are contiguous).  The backward finds both in `meta`."""
+    import torch.distributed as dist
+
+    from . import parallel
+    group = meta["group"]
+    dev = indexes.device
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    M = int(touched_count)
+    off = scratch_offset + nv.lib().gs_map_touched_offset(n, max(num_tiles, 1))
+    touched = scratch[off:off + 4 * M].view(torch.int32)
+    if meta["grad_mode"] == "sharded":
+        touched = torch.sort(touched)[0]  # rows ascend with the Gaussian index: owners become contiguous
+        chunk = -(-n // world)
+        bounds = torch.arange(world + 1, device=dev, dtype=torch.int64) * chunk
+        cuts = torch.searchsorted(indexes[touched.long()], bounds)
+        counts = (cuts[1:] - cuts[:-1]).contiguous()
+    else:
+        touched = touched.clone()
+        counts = torch.full((1,), M, dtype=torch.int64, device=dev)
+    meta["touched"] = touched
+    meta["sizes"] = parallel.SizesFuture(counts, group) if world > 1 else None
 
 
 def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_var):
@@ -275,7 +308,35 @@ def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_
         g_feat, g_feat_stride = _off(rows, 7 + col0), RS     # dL/d(SH colour) columns
         g_pts, g_pts_stride = rows, RS                        # dL/d(points) [+ depth feature] columns
         wait_points = None
-        if m["shard"] is not None:
+        sparse = m["shard"] is not None and m.get("exchange") == "sparse" and m.get("sizes") is not None
+        if sparse:
+            # Sparse exchange (parallel.py): one entry [row, 7 + F gradient words] per splat that can reach this rank's
+            # rows -- the mapper's own list -- instead of the dense rows, 7/8 of which are zeros on every rank of 8.
+            from . import parallel
+            rows_n = rows.shape[0]
+            touched, M = m["touched"], int(m["touched"].shape[0])
+            width = parallel.ENTRY_HEAD + F
+            entries = torch.empty((max(M, 1), width), dtype=torch.float32, device=dev)
+            nv.check(lib.gs_shard_pack_sparse(M, nv.ptr(touched), F, col0, nv.ptr(rows),
+                                              nv.ptr(feats) if m["degree"] >= 0 else None, nv.ptr(entries), s),
+                     "gs_shard_pack_sparse")
+            table = m["sizes"].result()
+            group = m["group"]
+            rank = torch.distributed.get_rank(group)
+            if m["grad_mode"] == "sharded":   # table[q][r] = entries rank q holds for owner r
+                lists = parallel.exchange_entries_sharded(entries, [int(x) for x in table[rank]],
+                                                          [int(table[q][rank]) for q in range(len(table))], group)
+            else:                             # table[q][0] = list length of rank q
+                lists = parallel.exchange_entries_replicated(entries, M, [int(t[0]) for t in table], group)
+            m["exchanged"] = dict(width=width, own=M, table=table)
+            pf = torch.zeros((rows_n, C), dtype=torch.float32, device=dev)
+            pp = torch.zeros((rows_n, 7 + col0), dtype=torch.float32, device=dev)
+            for ent, cnt in lists:  # one list after the other, in rank order: the same sums on every rank
+                nv.check(lib.gs_shard_add_sparse(cnt, nv.ptr(ent), F, col0, rows_n, nv.ptr(pf), nv.ptr(pp), s),
+                         "gs_shard_add_sparse")
+            g_feat, g_feat_stride = nv.ptr(pf), C
+            g_pts, g_pts_stride = pp, 7 + col0
+        elif m["shard"] is not None:
             # Every rank rendered different rows: the per-Gaussian partial gradients are summed over the
             # ranks, 4*(7+F) bytes per visible Gaussian in all.  Two collectives, colour columns first: the SH
             # adjoint only needs those and runs while the splat columns are still in flight.
@@ -293,19 +354,29 @@ def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_
             publish(rows)
             add_attached(rows)
 
-        d_feature = torch.empty_like(feature)
+        # grad_mode "sharded": the adjoints run on this rank's index range [lo, hi) only -- the same kernels on base
+        # pointers moved to row `lo` (every array they touch is indexed by the Gaussian, the gradient rows through
+        # slot_of) -- and the gradients come out range-shaped
+        lo, hi = m["owned_range"] if m.get("owned_range") is not None else (0, n)
+        nr = hi - lo
+        need_T, need_proj = ctx.camera_grads
+
+        def at(t, row):  # pointer to row `row` of a per-Gaussian tensor
+            return ctypes.c_void_p(t.data_ptr() + row * t.stride(0) * t.element_size())
+
+        d_feature = torch.empty((nr, *feature.shape[1:]), dtype=torch.float32, device=dev)
         # camera matrix under optimisation: the SH view direction depends on the camera centre = inverse(T)[:3, 3]
         # (reference perspective/params.py:76-78), so the SH adjoint also returns dL/d(centre) and the 4x4 inverse is
         # differentiated below (pose refinement is rare: a handful of tiny torch ops, off the common path)
         d_centre = None
-        if m["degree"] >= 1 and ctx.needs_input_grad[5]:
+        if m["degree"] >= 1 and need_T:
             d_centre = torch.zeros((3,), dtype=torch.float32, device=dev)
         if m["degree"] >= 0:
-            nv.check(lib.gs_sh_bwd(n, V, C, m["degree"], nv.ptr(feature), nv.ptr(position), nv.ptr(indexes), 1,
-                                   nv.ptr(slot_of), nv.ptr(cam_pos), g_feat, g_feat_stride, _off(feats, col0), F,
+            nv.check(lib.gs_sh_bwd(nr, V, C, m["degree"], at(feature, lo), at(position, lo), nv.ptr(indexes), 1,
+                                   at(slot_of, lo), nv.ptr(cam_pos), g_feat, g_feat_stride, _off(feats, col0), F,
                                    nv.ptr(d_feature), None, nv.ptr(d_centre), s), "gs_sh_bwd")
         else:
-            nv.check(lib.gs_feature_gather_bwd(n, C, nv.ptr(slot_of), g_feat, g_feat_stride, nv.ptr(d_feature), s),
+            nv.check(lib.gs_feature_gather_bwd(nr, C, at(slot_of, lo), g_feat, g_feat_stride, nv.ptr(d_feature), s),
                      "gs_feature_gather_bwd")
         if wait_points is not None:
             wait_points.wait()
@@ -313,19 +384,19 @@ def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_
             publish(g_pts)
             add_attached(g_pts)
 
-        need_T, need_proj = ctx.needs_input_grad[5], ctx.needs_input_grad[6]
-        d_pos, d_ls = torch.empty_like(position), torch.empty_like(log_scaling)
-        d_rot, d_al = torch.empty_like(rotation), torch.empty_like(alpha_logit)
+        f32r = dict(dtype=torch.float32, device=dev)
+        d_pos, d_ls = torch.empty((nr, 3), **f32r), torch.empty((nr, 3), **f32r)
+        d_rot, d_al = torch.empty((nr, 4), **f32r), torch.empty((nr, 1), **f32r)
         d_T = torch.empty((4, 4), dtype=torch.float32, device=dev) if need_T else None
         d_proj = torch.empty((4,), dtype=torch.float32, device=dev) if need_proj else None
-        nbytes = lib.gs_project_bwd_scratch_bytes(n) if (need_T or need_proj) else 0
+        nbytes = lib.gs_project_bwd_scratch_bytes(nr) if (need_T or need_proj) else 0
         scratch = torch.empty((max(nbytes, 1),), dtype=torch.uint8, device=dev)
         if m["render_depth"]:
             gd, gd2, gstride = _off(g_pts, 7), _off(g_pts, 8), g_pts_stride
         else:
             gd, gd2, gstride = nv.ptr(extra_depth), None, 1
-        nv.check(lib.gs_project_bwd(n, V, nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation), nv.ptr(alpha_logit),
-                                    nv.ptr(T), nv.ptr(proj), w, m["full_h"], cfg, nv.ptr(slot_of), nv.ptr(g_pts),
+        nv.check(lib.gs_project_bwd(nr, V, at(position, lo), at(log_scaling, lo), at(rotation, lo), at(alpha_logit, lo),
+                                    nv.ptr(T), nv.ptr(proj), w, m["full_h"], cfg, at(slot_of, lo), nv.ptr(g_pts),
                                     g_pts_stride, gd, gd2, gstride, nv.ptr(d_pos), nv.ptr(d_ls), nv.ptr(d_rot),
                                     nv.ptr(d_al), nv.ptr(d_T), nv.ptr(d_proj), nv.ptr(scratch), nbytes, s),
                  "gs_project_bwd")
@@ -370,6 +441,7 @@ def _frame_for(n, C, degree, w, full_h, depth_range, render_depth, use_depth16, 
             frame.shard = nv.GsRowShard(int(shard.row_begin), int(shard.row_end), int(shard.band), int(shard.period),
                                         int(shard.phase))
         frame.cfg = nv.make_config(config)
+        frame.depth_forward_cut = nv.make_config(config, cut_scale=float(depth_range[1]) ** 2).forward_cut
         layout = nv.GsFrameLayout()
         nv.check(nv.lib().gs_frame_layout(ctypes.byref(frame), ctypes.byref(layout)), "gs_frame_layout")
         if len(_FRAMES) > 256:
@@ -404,7 +476,8 @@ class _FrameRender(torch.autograd.Function):
     @nv.on_tensor_device
     def forward(ctx, position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                 image_size, depth_range, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                render_median: bool, shard, group, holder, key, k_cap: int, tile_hint: int):
+                render_median: bool, shard, group, holder, exchange: str, grad_mode: str, owned_range, key,
+                k_cap: int, tile_hint: int):
         nv.require_device(position, log_scaling, rotation, alpha_logit, feature, T_camera_world, projection,
                           what="render_gaussians")
         lib = nv.lib()
@@ -465,7 +538,13 @@ class _FrameRender(torch.autograd.Function):
             median = view(L.median, (h, w))
 
         ctx.meta = dict(n=n, V=V, K=K, w=w, h=h, full_h=full_h, F=F, C=C, col0=F - C, degree=degree, config=config,
-                        render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]))
+                        render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]),
+                        exchange=exchange, grad_mode=grad_mode, owned_range=owned_range)
+        if shard is not None and exchange == "sparse":
+            T_tiles = L.tiles_x * L.tiles_y
+            _start_sparse_exchange(ctx.meta, n, T_tiles, host[5] if T_tiles > 0 else 0,
+                                   ws.view(torch.int64).as_strided((n,), (1,), L.indexes // 8), scratch, L.s_stage)
+        ctx.camera_grads = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])
         ctx.frame, ctx.layout = frame, L
         ctx.heur = heur
         ctx.holder = holder
@@ -504,7 +583,7 @@ class _FrameRender(torch.autograd.Function):
                      vw(f32_, L.image, (h_, w_, F_)), vw(f32_, L.alpha, (h_, w_)),
                      vw(f32_, L.img_depth, (h_, w_)) if m["render_depth"] else _empty(position.device, (0,)),
                      vw(i32_, L.tile_order, (T_tiles,)), vw(i32_, L.counts, (8,)))
-            return _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 12
+            return _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 15
         lib = nv.lib()
         dev = position.device
         n, V, K, F = m["n"], m["V"], m["K"], m["F"]
@@ -563,7 +642,48 @@ class _FrameRender(torch.autograd.Function):
                 dY = torch.zeros((4, 4), dtype=torch.float64)
                 dY[:3, 3] = d_centre.cpu().double()
                 d_T = d_T + (-(Y.T @ dY @ Y.T)).to(device=dev, dtype=torch.float32)
-        return (d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj) + (None,) * 12
+        return (d_pos, d_ls, d_rot, d_al, d_feature, d_T, d_proj) + (None,) * 15
+
+
+class _OwnedRender(torch.autograd.Function):
+    """grad_mode "sharded" (parallel.py): the replicated Gaussians are DATA here; what is differentiated are this rank's
+    own rows [lo, hi) of them, held as separate leaf tensors by a sharded optimizer (`owned`: their values are taken to
+    be the corresponding rows of the replicated tensors).  Forward: the sharded frame as usual.  Backward: partial
+    gradients go to their owners through one all-to-all, the SH / projection adjoints run on the owned range only and
+    the gradients come out range-shaped -- no all-gather of gradients, no (N, ...) zero rows written."""
+
+    @staticmethod
+    @nv.on_tensor_device
+    def forward(ctx, o_position, o_log_scaling, o_rotation, o_alpha_logit, o_feature, full, rest, key, k_cap, tile_hint):
+        ctx.needs_full = (True,) * 5 + (False, False)
+        if k_cap:
+            return _FrameRender.forward(_Proxy(ctx), *full, *rest, key, k_cap, tile_hint)
+        return _FusedRender.forward(_Proxy(ctx), *full, *rest)
+
+    @staticmethod
+    @nv.on_tensor_device
+    def backward(ctx, g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth, g_img_var,
+                 _g_median=None):
+        inner = _FrameRender if hasattr(ctx, "frame") else _FusedRender
+        grads = inner.backward(_Proxy(ctx), g_image, _g_alpha, g_points, g_depth, _g_idx, _g_vis, _g_heur, g_img_depth,
+                               g_img_var, _g_median)
+        return tuple(grads[:5]) + (None,) * 5
+
+
+class _Proxy:
+    """lets the forward / backward bodies of the two Functions above run on behalf of _OwnedRender: same attributes,
+    but the differentiable inputs are the five Gaussian tensors and never the camera"""
+
+    def __init__(self, ctx):
+        object.__setattr__(self, "_ctx", ctx)
+
+    def __getattr__(self, name):
+        if name == "needs_input_grad":
+            return object.__getattribute__(self, "_ctx").needs_full
+        return getattr(object.__getattribute__(self, "_ctx"), name)
+
+    def __setattr__(self, name, value):
+        setattr(object.__getattribute__(self, "_ctx"), name, value)
 
 
 def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth: bool) -> bool:
@@ -579,7 +699,8 @@ def fused_supported(gaussians, camera_params, use_sh: bool, render_median_depth:
 
 
 def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: bool, use_depth16: bool,
-                 shard=None, group=None, render_median_depth: bool = False):
+                 shard=None, group=None, render_median_depth: bool = False, exchange: str = "dense",
+                 grad_mode: str = "replicated", owned=None, owned_range=None):
     """shard (parallel.RowShard): render only the tile rows this rank owns; the images then hold those pixel rows,
     everything per-Gaussian (`gaussians2d` included) stays in full-image coordinates.
     See parallel.render_gaussians_sharded."""
@@ -590,16 +711,29 @@ def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: b
     args = (gaussians.position.contiguous(), gaussians.log_scaling.contiguous(), gaussians.rotation.contiguous(),
             gaussians.alpha_logit.contiguous(), gaussians.feature.contiguous(), camera_params.T_camera_world,
             camera_params.projection, camera_params.image_size, camera_params.depth_range, config, render_depth,
-            use_depth16, render_median_depth, shard, group, holder)
+            use_depth16, render_median_depth, shard, group, holder, exchange, grad_mode, owned_range)
     size = camera_params.image_size
     key = (args[0].shape[0], int(size[0]), int(size[1]), shard, config.tile_size, bool(use_depth16))
     hint = _K_HINT.get(key)
     outs = None
     if hint is None and FRAME_CALLS == "always":  # tests: size the frame by an untracked staged pass first
         with torch.no_grad():
-            _FusedRender.apply(*args)
+            _FusedRender.apply(*args[:16], "dense", "replicated", None)
         hint = _K_HINT.get(key)
-    if hint is not None and FRAME_CALLS:
+    if owned is not None:
+        # grad_mode "sharded": gradients flow to the rank's own rows (range-shaped leaf tensors), see _OwnedRender
+        k_cap = tile_hint = 0
+        if hint is not None and FRAME_CALLS:
+            k_cap = -(-(int(hint[0] * 1.25) + 4096) // 65536) * 65536
+            tile_hint = next((c for c in (256, 512, 1024, 2048) if hint[1] <= c), 4096)
+        own = (owned.position.contiguous(), owned.log_scaling.contiguous(), owned.rotation.contiguous(),
+               owned.alpha_logit.contiguous(), owned.feature.contiguous())
+        full = tuple(t.detach() for t in args[:7])
+        try:
+            outs = _OwnedRender.apply(*own, full, args[7:], key, k_cap, tile_hint)
+        except _Overflow:
+            outs = _OwnedRender.apply(*own, full, args[7:], key, 0, 0)
+    elif hint is not None and FRAME_CALLS:
         # one C-ABI call per direction; capacities rounded up to a few classes so that the cached frame descriptors
         # and workspace layouts are reused from frame to frame
         k_cap = -(-(int(hint[0] * 1.25) + 4096) // 65536) * 65536

@@ -137,13 +137,152 @@ def _reduce_partial_gradients(colour: torch.Tensor, splat: torch.Tensor, group, 
     return second
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# Sparse exchange.  A rank's partial gradients cover only the splats that can reach its tile rows: of the rows an
+# 8-rank dense all-reduce sums, 7/8 are zeros on every rank.  Each rank instead contributes a LIST of entries
+# [row id (int32 bits), 7 + F gradient words] for the splats it touched:
+#   grad_mode "replicated": the lists are all-gathered (padded to the longest, whose length every rank knows from an
+#       all-gather of the list lengths issued during the forward) and every rank adds them into zeroed dense rows, one
+#       list after the other IN RANK ORDER -- plain read-modify-write, the rows of one list are distinct -- so that all
+#       ranks hold the same sums bit for bit (a replicated optimizer must not drift);
+#   grad_mode "sharded": rank r is the owner of the Gaussians [lo_r, hi_r) (`owned_range`); the entries, grouped by
+#       owner, go through ONE all-to-all with per-destination counts (known from the forward as well), the owner adds
+#       what it received in source-rank order and runs the SH / projection adjoints on ITS index range only (SURVEY 8e's
+#       alternative for a sharded optimizer: `reduce_scatter` + sharded a14; no all-gather of gradients).
+# Exchanged bytes per rank (F = 3, 44-byte entries, M ~ V / R (1 + border) touched splats): replicated sends 44 M and
+# receives 44 (R - 1) M, sharded sends and receives 44 M (R - 1) / R, against 2 (R - 1) / R * 40 V each way for the ring
+# all-reduce of the dense rows.
+EXCHANGES = ("dense", "sparse")
+GRAD_MODES = ("replicated", "sharded")
+ENTRY_HEAD = 8  # words of an entry in front of the F feature gradients: row id + 7 splat gradients
+
+
+def owned_range(rank: int, world: int, n: int) -> Tuple[int, int]:
+    """the Gaussians [lo, hi) whose gradients rank `rank` reduces and owns in grad_mode "sharded" """
+    chunk = -(-int(n) // max(int(world), 1))
+    lo = min(rank * chunk, n)
+    return lo, min(lo + chunk, n)
+
+
+def split_owned(gaussians: Gaussians3D, rank: int, world: int) -> Gaussians3D:
+    """this rank's rows of the replicated Gaussians as independent leaf tensors (what a sharded optimizer holds)"""
+    lo, hi = owned_range(rank, world, gaussians.position.shape[0])
+    return gaussians.apply(lambda t: t[lo:hi].detach().clone())
+
+
+def gather_owned(owned: Gaussians3D, n: int, group=None) -> Gaussians3D:
+    """all-gather the ranks' owned rows into the replicated (detached) Gaussians every rank projects -- the step a
+    sharded optimizer needs after its update (236 B / Gaussian at SH degree 3; the price of not all-gathering gradients)"""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return owned.apply(lambda t: t.detach())
+    chunk = -(-int(n) // world)
+
+    def gather(t):
+        pad = t.new_zeros((chunk, *t.shape[1:]))
+        pad[:t.shape[0]] = t.detach()
+        parts = [torch.empty_like(pad) for _ in range(world)]
+        dist.all_gather(parts, pad, group=group)
+        return torch.cat(parts, 0)[:n].contiguous()
+    return owned.apply(gather)
+
+
+def exchange_sizes(counts: torch.Tensor, group=None, async_op: bool = False):
+    """all-gather of every rank's count vector (k int64: its list length, or its per-destination counts).  Returns
+    (matrix (world, k), handle or None)"""
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(counts) for _ in range(world)]
+    handle = dist.all_gather(parts, counts, group=group, async_op=async_op)
+    return parts, handle
+
+
+_PINNED_SIZES = {}  # (world, k) -> ring of pinned int64 buffers
+
+
+class SizesFuture:
+    """The list lengths of a sparse exchange are known when the mapper has run, i.e. during the FORWARD: they are
+    all-gathered there (asynchronously) and parked in pinned host memory, so that the backward finds them without a
+    device synchronisation of its own."""
+
+    def __init__(self, counts: torch.Tensor, group=None):
+        self.world = dist.get_world_size(group)
+        parts, handle = exchange_sizes(counts, group, async_op=True)
+        handle.wait()  # NCCL: the current stream waits; gloo: the host does
+        table = torch.stack(parts)
+        if table.is_cuda:
+            key = (table.device.index, self.world, int(counts.numel()))
+            ring = _PINNED_SIZES.get(key)
+            if ring is None:
+                ring = _PINNED_SIZES[key] = dict(bufs=[torch.empty(table.shape, dtype=table.dtype).pin_memory()
+                                                       for _ in range(4)], at=0)
+            ring["at"] = (ring["at"] + 1) % len(ring["bufs"])
+            self.host = ring["bufs"][ring["at"]]
+            self.host.copy_(table, non_blocking=True)
+            self.event = torch.cuda.Event()
+            self.event.record()
+        else:
+            self.host, self.event = table, None
+
+    def result(self) -> List[List[int]]:
+        if self.event is not None:
+            self.event.synchronize()
+        return self.host.tolist()
+
+
+def exchange_entries_replicated(entries: torch.Tensor, count: int, sizes: List[int], group=None):
+    """entries (>= count, W): this rank's list.  Returns [(entries of rank q, count of rank q)] for every rank, in
+    rank order (padded all-gather: every rank contributes max(sizes) rows)."""
+    world = dist.get_world_size(group)
+    longest = max(max(sizes), 1)
+    own = entries.new_empty((longest, entries.shape[1]))
+    own[:count] = entries[:count]
+    parts = [torch.empty_like(own) for _ in range(world)]
+    dist.all_gather(parts, own, group=group)
+    return [(parts[q], int(sizes[q])) for q in range(world)]
+
+
+def exchange_entries_sharded(entries: torch.Tensor, send_counts: List[int], recv_counts: List[int], group=None):
+    """entries (sum(send_counts), W) grouped by destination rank.  Returns [(entries from rank q, count)] in rank order
+    (one all-to-all with per-destination split sizes)."""
+    world = dist.get_world_size(group)
+    width = entries.shape[1]
+    recv = entries.new_empty((max(sum(recv_counts), 1), width))
+    dist.all_to_all_single(recv[:sum(recv_counts)], entries[:sum(send_counts)].contiguous(),
+                           output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts), group=group)
+    out, at = [], 0
+    for q in range(world):
+        out.append((recv[at:at + recv_counts[q]], int(recv_counts[q])))
+        at += recv_counts[q]
+    return out
+
+
+def exchanged_bytes(mode: str, grad_mode: str, world: int, visible: int, touched: List[int], features: int,
+                    rank: int = 0) -> dict:
+    """payload bytes rank `rank` sends and receives in a frame's exchange step (exact without any hardware: list
+    lengths and V are all it depends on).  dense: the ring all-reduce of (V, 7 + F) rows."""
+    dense = 4 * (7 + features) * visible
+    if mode == "dense" or world == 1:
+        wire = int(2 * (world - 1) / max(world, 1) * dense)
+        return dict(mode="dense", payload=dense, sent=wire, received=wire)
+    entry = 4 * (ENTRY_HEAD + features)
+    if grad_mode == "sharded":  # a uniform split over the owners is what a random index order gives
+        sent = int(entry * touched[rank] * (world - 1) / world)
+        recv = int(entry * sum(t for q, t in enumerate(touched) if q != rank) / world)
+        return dict(mode="sparse/sharded", payload=entry * touched[rank], sent=sent, received=recv, dense_payload=dense)
+    longest = max(touched)
+    return dict(mode="sparse/replicated", payload=entry * touched[rank], sent=entry * longest,
+                received=entry * longest * (world - 1), dense_payload=dense)
+
+
 class _AllReduceGrads(torch.autograd.Function):
     """Identity in the forward; in the backward the partial gradients of (gaussians2d, features, depths) are summed
     over the process group with the two collectives of `_reduce_partial_gradients`."""
 
     @staticmethod
-    def forward(ctx, group, depth_cols, gaussians2d, features, depths):
+    def forward(ctx, group, depth_cols, gaussians2d, features, depths, exchange="dense", row_owner=None):
+        """row_owner (V int64, grad_mode "sharded"): the rank that owns each visible Gaussian"""
         ctx.group, ctx.depth_cols, ctx.channels = group, int(depth_cols), int(features.shape[1])
+        ctx.exchange, ctx.row_owner = exchange, row_owner
         return gaussians2d.view_as(gaussians2d), features.view_as(features), depths.view_as(depths)
 
     @staticmethod
@@ -163,12 +302,35 @@ class _AllReduceGrads(torch.autograd.Function):
             splat[:v, :7] = g_points
         if g_depths is not None and ctx.depth_cols:
             splat[:v, 7] = g_depths.reshape(-1)
-        second = _reduce_partial_gradients(colour, splat, ctx.group)
-        if second is not None:
-            second.wait()
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(ctx.group) > 1
+        if ctx.exchange == "sparse" and multi:
+            # the protocol of the fused frame (module comment), on torch operators: the composed path has no mapper
+            # list at hand, so "touched" = the rows that received any gradient
+            packed = torch.cat([splat, colour], dim=1)
+            touched = (packed != 0).any(dim=1).nonzero().reshape(-1)
+            ids = touched.to(torch.int32).view(torch.float32).reshape(-1, 1)
+            entries = torch.cat([ids, packed[touched]], dim=1).contiguous()
+            rank, world = dist.get_rank(ctx.group), dist.get_world_size(ctx.group)
+            if ctx.row_owner is not None:
+                send = torch.bincount(ctx.row_owner[touched], minlength=world)  # touched ascends -> owners contiguous
+                table = [t.tolist() for t in exchange_sizes(send, ctx.group)[0]]
+                lists = exchange_entries_sharded(entries, table[rank], [table[q][rank] for q in range(world)], ctx.group)
+            else:
+                count = torch.tensor([touched.shape[0]], dtype=torch.int64, device=ref.device)
+                sizes = [int(t.item()) for t in exchange_sizes(count, ctx.group)[0]]
+                lists = exchange_entries_replicated(entries, int(touched.shape[0]), sizes, ctx.group)
+            total = torch.zeros_like(packed)
+            for ent, cnt in lists:  # rank order, distinct rows inside a list: the same sums on every rank
+                if cnt:
+                    total[ent[:cnt, 0].contiguous().view(torch.int32).long()] += ent[:cnt, 1:]
+            splat, colour = total[:, :width].contiguous(), total[:, width:].contiguous()
+        else:
+            second = _reduce_partial_gradients(colour, splat, ctx.group)
+            if second is not None:
+                second.wait()
         g_d = splat[:v, 7:8].contiguous() if ctx.depth_cols else \
             (g_depths if g_depths is not None else None)
-        return None, None, splat[:v, :7].contiguous(), colour[:v], g_d
+        return None, None, splat[:v, :7].contiguous(), colour[:v], g_d, None, None
 
 
 def default_ops() -> SimpleNamespace:
@@ -185,14 +347,27 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
                              config: RasterConfig = RasterConfig(), use_sh: bool = False, render_depth: bool = False,
                              use_depth16: bool = False, group=None, rank: Optional[int] = None,
                              world_size: Optional[int] = None, ops: Optional[SimpleNamespace] = None,
-                             interleave: int = 0):
+                             interleave: int = 0, exchange: str = "dense", grad_mode: str = "replicated",
+                             owned: Optional[Gaussians3D] = None):
     """Render this rank's rows of the frame.  Returns a `Rendering` whose image tensors hold the owned pixel rows
     of the full image in ascending order: `rendering.bands` lists them as [(y0, y1), ...] (`rendering.strip` is the
     first band -- the whole share of a contiguous shard; index a full-size target with
     `owned_pixel_rows(rendering.bands)`).  After `.backward()` of a loss summed over the ranks, every rank holds the
     full parameter gradients.  `gaussians2d` is in full-image coordinates, identical on every rank.
-    `point_visibility` / `point_heuristic` are this rank's share: `reduce_point_statistics` sums them."""
+    `point_visibility` / `point_heuristic` are this rank's share: `reduce_point_statistics` sums them.
+
+    exchange: "dense" = all-reduce of the (V, 7 + F) partial gradient rows; "sparse" = lists of the touched rows only
+    (module comment above `EXCHANGES`).  grad_mode "sharded" (implies the sparse exchange): for a sharded optimizer --
+    `gaussians` is then the replicated, detached set every rank projects and `owned` (`split_owned`) this rank's rows
+    [lo, hi) = `owned_range(rank, world, N)` of it as leaf tensors; after `.backward()` those hold the COMPLETE
+    gradients of the Gaussians this rank owns, and nothing else is written (no camera gradients in this mode)."""
     from .renderer import Rendering, compute_depth_variance
+    if exchange not in EXCHANGES or grad_mode not in GRAD_MODES:
+        raise ValueError(f"exchange {exchange!r} / grad_mode {grad_mode!r}: expected one of {EXCHANGES} / {GRAD_MODES}")
+    if (grad_mode == "sharded") != (owned is not None):
+        raise ValueError('grad_mode "sharded" takes the rank\'s own rows as `owned` (parallel.split_owned), and only it does')
+    if grad_mode == "sharded":
+        exchange = "sparse"
     if rank is None:
         rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world_size is None:
@@ -212,9 +387,20 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
         from .fused import fused_supported, render_fused
         if fused_supported(gaussians, camera_params, use_sh, False):
             # the fused frame (fused.py) on this rank's rows; its backward carries the exchange step
+            rng = owned_range(rank, world_size, gaussians.position.shape[0]) if owned is not None else None
             return tag(render_fused(gaussians, camera_params, config, render_depth, use_depth16, shard=shard,
-                                    group=group))
+                                    group=group, exchange=exchange, grad_mode=grad_mode, owned=owned, owned_range=rng))
         ops = default_ops()
+
+    row_owner = None
+    if owned is not None:
+        # composed path: splice the owned leaf rows into the replicated data, so that autograd hands the range-shaped
+        # gradients back through the concatenation
+        lo, hi = owned_range(rank, world_size, gaussians.position.shape[0])
+        data = gaussians.apply(lambda t: t.detach())
+        gaussians = Gaussians3D(**{k: torch.cat([getattr(data, k)[:lo], getattr(owned, k), getattr(data, k)[hi:]], 0)
+                                   for k in ("position", "log_scaling", "rotation", "alpha_logit", "feature")},
+                                batch_size=data.batch_size)
 
     gaussians2d, depths, indexes, ndc_depths = ops.project_with_ndc(
         *gaussians.shape_tensors(), camera_params.T_camera_world, camera_params.projection,
@@ -226,8 +412,11 @@ def render_gaussians_sharded(gaussians: Gaussians3D, camera_params: CameraParams
         features = gaussians.feature[indexes]
 
     # everything upstream of this point is replicated; gradients arriving here are partial sums
+    if owned is not None:
+        chunk = -(-gaussians.position.shape[0] // world_size)
+        row_owner = indexes // chunk
     g2d_r, features_r, depths_r = _AllReduceGrads.apply(group, 2 if render_depth else 0, gaussians2d, features,
-                                                        depths)
+                                                        depths, exchange, row_owner)
     raster_features = torch.cat([depths_r, depths_r ** 2, features_r], dim=1) if render_depth else features_r
     F = raster_features.shape[1]
 

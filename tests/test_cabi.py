@@ -109,7 +109,7 @@ def test_frame_layout_is_computed_on_the_host():
     layouts seen through ctypes are the header's; bad frames are refused before anything is launched"""
     lib = _native.lib()
     cfg = _native.GsRasterConfig(tile_size=16, alpha_threshold=1 / 255., forward_cut=2.0 ** -20)
-    assert ctypes.sizeof(_native.GsFrame) == 152 and ctypes.sizeof(_native.GsFrameLayout) == 29 * 8 + 5 * 4 + 4
+    assert ctypes.sizeof(_native.GsFrame) == 160 and ctypes.sizeof(_native.GsFrameLayout) == 29 * 8 + 5 * 4 + 4
 
     def frame(**kw):
         f = _native.GsFrame(n=1000, channels=3, sh_degree=3, width=100, height=70, near_plane=0.1, far_plane=100.0,

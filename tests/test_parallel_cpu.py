@@ -87,6 +87,78 @@ def test_sharded_render_matches_single_process(tmp_path, world, size, n, depth_m
     assert sorted(np.concatenate(covered).tolist()) == list(range(size[1]))
 
 
+def _run_modes(rank, world, port, size, n, depth_mode, interleave, exchange, grad_mode, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, cam, gi, gdm = _scene(size, n, depth_mode)
+        cfg = RasterConfig()
+        owned = None
+        if grad_mode == "sharded":
+            owned = parallel.split_owned(g, rank, world).requires_grad_(True)
+        else:
+            g = g.requires_grad_(True)
+        r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=depth_mode, ops=oracle_ops.OPS,
+                                              interleave=interleave, exchange=exchange, grad_mode=grad_mode, owned=owned)
+        rows = parallel.owned_pixel_rows(r.bands)
+        loss = (r.image * gi[rows]).sum()
+        if depth_mode:
+            loss = loss + (r.depth * gdm[rows]).sum()
+        loss.backward()
+        holder = owned if owned is not None else g
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), **{f"d_{k}": v.grad.numpy() for k, v in holder.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,size,n,depth_mode,interleave,exchange,grad_mode", [
+    (2, (96, 80), 1500, False, 0, "sparse", "replicated"),
+    (3, (64, 112), 800, True, 2, "sparse", "replicated"),
+    (3, (64, 30), 400, True, 0, "sparse", "replicated"),   # rank 2 owns no tile row: an empty list, same collectives
+    (2, (96, 80), 1500, False, 1, "sparse", "sharded"),
+    (3, (64, 112), 803, True, 0, "sparse", "sharded"),      # 803 Gaussians over 3 owners: ranges 268 / 268 / 267
+])
+def test_sparse_exchange_and_sharded_gradients(tmp_path, world, size, n, depth_mode, interleave, exchange, grad_mode):
+    """exchange="sparse": every rank ends with the single-process gradients, and with the SAME ones bit for bit (the
+    lists are added in rank order); grad_mode="sharded": rank r ends with the complete gradients of the Gaussians
+    owned_range(r) -- range-shaped, on its `owned` leaf tensors -- through one all-to-all."""
+    mp.spawn(_run_modes, args=(world, _free_port(), size, n, depth_mode, interleave, exchange, grad_mode,
+                               str(tmp_path)), nprocs=world, join=True)
+    g, cam, gi, gdm = _scene(size, n, depth_mode)
+    g = g.requires_grad_(True)
+    r = parallel.render_gaussians_sharded(g, cam, RasterConfig(), use_sh=True, render_depth=depth_mode,
+                                          ops=oracle_ops.OPS, rank=0, world_size=1)
+    loss = (r.image * gi).sum()
+    if depth_mode:
+        loss = loss + (r.depth * gdm).sum()
+    loss.backward()
+    first = np.load(tmp_path / "rank0.npz")
+    for rank in range(world):
+        z = np.load(tmp_path / f"rank{rank}.npz")
+        lo, hi = parallel.owned_range(rank, world, n) if grad_mode == "sharded" else (0, n)
+        for k, v in g.items():
+            ref = v.grad.numpy()[lo:hi]
+            assert z[f"d_{k}"].shape == ref.shape
+            assert np.allclose(z[f"d_{k}"], ref, rtol=1e-4, atol=1e-5 * max(1.0, np.abs(v.grad.numpy()).max())), (rank, k)
+            if grad_mode == "replicated":
+                assert np.array_equal(z[f"d_{k}"], first[f"d_{k}"]), "replicas must not drift"
+    assert [parallel.owned_range(r, 3, 803) for r in range(3)] == [(0, 268), (268, 536), (536, 803)]
+
+
+def test_exchanged_bytes_accounting():
+    """the bench line's exchange figures are arithmetic on list lengths: dense ring all-reduce vs the two sparse modes"""
+    V, F, world = 6_000_000, 3, 8
+    touched = [int(V / world * 1.15)] * world
+    dense = parallel.exchanged_bytes("dense", "replicated", world, V, touched, F)
+    assert dense["payload"] == 40 * V and dense["sent"] == int(2 * 7 / 8 * 40 * V)
+    sp = parallel.exchanged_bytes("sparse", "replicated", world, V, touched, F)
+    sh = parallel.exchanged_bytes("sparse", "sharded", world, V, touched, F)
+    assert sp["sent"] == 44 * touched[0] and sp["received"] == 44 * touched[0] * 7
+    assert sh["sent"] == int(44 * touched[0] * 7 / 8) and sh["sent"] < 0.1 * dense["sent"]
+    assert sp["received"] < 0.75 * dense["received"]
+
+
 def test_strip_partition():
     for world in (1, 2, 3, 8):
         for rows in (1, 7, 8, 128, 129):
