@@ -176,6 +176,12 @@ int gs_shard_pack_sparse(int64_t m, const int32_t* touched, int32_t num_features
                          const float* grad_rows, const float* features, float* entries, void* stream);
 int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_features, int32_t colour_col0, int64_t v,
                         float* colour_out, float* splat_out, void* stream);
+/* Sharded gradients (grad_mode "sharded"): rank r owns the Gaussians [r chunk, (r + 1) chunk), chunk = ceil(n / world).
+ * Groups the m touched rows by the owner of their Gaussian (indexes (v) int64 from gs_project_fwd): grouped (m int32) =
+ * the rows of owner 0, then of owner 1, ...; counts (world int64) = the group sizes, i.e. the send counts of the
+ * all-to-all.  scratch: 8 bytes per rank.  world <= 64. */
+int gs_shard_group_by_owner(int64_t m, const int32_t* touched, const int64_t* indexes, int64_t n, int32_t world,
+                            int64_t* counts, int32_t* grouped, void* scratch, int64_t scratch_bytes, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,

@@ -162,7 +162,6 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
   __shared__ int s_wave[16];
   __shared__ int s_bin[1024];
   const int t = threadIdx.x;
-  constexpr int U = 8;  // rounds whose loads are issued together (a load behind every barrier would cost its latency each)
   if (blockIdx.x == 0) {
     // Round 3: every thread owns PER consecutive tiles of a round (64 bytes: four 16-byte loads), scans them serially
     // in registers and takes part in ONE workgroup scan of the per-thread totals per 16 384 tiles -- two barriers per
@@ -238,23 +237,36 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
     }
     return;
   }
-  // ---- workgroup 1: counting sort of the tiles by descending overlap count (1024 bins, the last one open-ended)
+  // ---- workgroup 1: counting sort of the tiles by descending overlap count (1024 bins, the last one open-ended).
+  // One pass over the histogram: a thread keeps its PER consecutive counts of a round in registers between the
+  // binning and the scatter (rounds beyond the first -- more than 16 384 tiles -- read the histogram twice).
+  constexpr int PER = 16;
   s_bin[t] = 0;
   __syncthreads();
   int sum = 0;
-  for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
-    int cs[U];
+  int c0[PER];
+  for (int base0 = 0; base0 < num_tiles; base0 += 1024 * PER) {
+    const int i0 = base0 + t * PER;
+    int c[PER];
+    if (i0 + PER <= num_tiles) {
+      const int4* src = reinterpret_cast<const int4*>(tile_hist + i0);
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base0 + u * 1024 + t;
-      cs[u] = i < num_tiles ? tile_hist[i] : -1;
+      for (int q = 0; q < PER / 4; ++q) {
+        const int4 v4 = src[q];
+        c[4 * q] = v4.x; c[4 * q + 1] = v4.y; c[4 * q + 2] = v4.z; c[4 * q + 3] = v4.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PER; ++j) c[j] = i0 + j < num_tiles ? tile_hist[i0 + j] : -1;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (cs[u] >= 0) {
-        sum += cs[u];
-        atomicAdd(&s_bin[min(cs[u], 1023)], 1);
+    for (int j = 0; j < PER; ++j) {
+      if (base0 == 0) c0[j] = c[j];
+      if (c[j] >= 0) {
+        sum += c[j];
+        atomicAdd(&s_bin[min(c[j], 1023)], 1);
       }
+    }
   }
   int unused, k_total;
   block_exclusive_scan(sum, s_wave, k_total);
@@ -274,16 +286,13 @@ __global__ __launch_bounds__(1024) void map_scan_kernel(int num_tiles, const int
     }
   }
   __syncthreads();
-  for (int base0 = 0; base0 < num_tiles; base0 += 1024 * U) {
-    int cs[U];
+  for (int base0 = 0; base0 < num_tiles; base0 += 1024 * PER) {
+    const int i0 = base0 + t * PER;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int i = base0 + u * 1024 + t;
-      cs[u] = i < num_tiles ? tile_hist[i] : -1;
+    for (int j = 0; j < PER; ++j) {
+      const int c = base0 == 0 ? c0[j] : (i0 + j < num_tiles ? tile_hist[i0 + j] : -1);
+      if (c >= 0 && i0 + j < num_tiles) tile_order[atomicAdd(&s_bin[min(c, 1023)], 1)] = i0 + j;
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (cs[u] >= 0) tile_order[atomicAdd(&s_bin[min(cs[u], 1023)], 1)] = base0 + u * 1024 + t;
   }
 }
 

@@ -81,19 +81,21 @@ struct BwdShape {
   static constexpr int ROW = ((9 + FP + 15) / 16) * 16;
   static constexpr int GEO_V4 = FULL ? 3 : 2;     // float4s of geometry per staged record ...
   static constexpr int REC_V4 = GEO_V4 + (FP + 3) / 4;  // ... followed by the feature row: one address, b128 reads
-  static constexpr int REC_F = 64 * 4 * REC_V4, ACC_STRIDE = NACC + 1, ACC_F = 64 * ACC_STRIDE;
+  // the per-splat totals are read back one lane per splat, so any ODD stride is conflict-free
+  static constexpr int REC_F = 64 * 4 * REC_V4, ACC_STRIDE = NACC | 1, ACC_F = 64 * ACC_STRIDE;
   static constexpr int OUT_STRIDE = ROW + 1, OUT_F = 64 * OUT_STRIDE;
   static constexpr int ARENA_F = (REC_F + ACC_F) > OUT_F ? (REC_F + ACC_F) : OUT_F;
 };
 
 #ifndef GS_BWD_LDS_REDUCE
-#define GS_BWD_LDS_REDUCE 0  // 1: the first 8 of 9 values of the lean F = 3 reduction are transposed through LDS
+#define GS_BWD_LDS_REDUCE 2  // 0: register butterfly; 1: 8 values through one 8-row LDS transpose; 2: two 4-row passes
 #endif
-constexpr int TR_STRIDE = 68;  // floats per value row of the transposition buffer (64 lanes + 4: b128 reads stay aligned)
+constexpr int TR_STRIDE = GS_BWD_LDS_REDUCE == 1 ? 68 : 64;  // floats per value row of the transposition buffer
+constexpr int TR_ROWS = GS_BWD_LDS_REDUCE == 1 ? 8 : 4;
 
 template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, int yout0, float* smem,
-                                                int* s_idx, float* s_tr) {
+                                                float* s_tr) {
   const int lane = threadIdx.x;
   constexpr bool FULL = MODE == 2, HEUR = MODE == 1;
   constexpr int NS = MODE == 2 ? 9 : MODE == 1 ? 8 : 6;  // sums per splat besides the F feature gradients
@@ -186,7 +188,6 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
       s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
       if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
-      s_idx[lane] = idx;
       const float* f = a.features + int64_t(idx) * a.F;
 #pragma unroll
       for (int q = 0; q < REC_V4 - GEO_V4; ++q) {
@@ -319,7 +320,41 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       if (any_grad) {
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
         // up owning value k stores it (one ds_write_b32 for all values of a chunk)
-        if (GS_BWD_LDS_REDUCE && NACC == 9) {
+        if (GS_BWD_LDS_REDUCE == 2 && NACC == 9) {
+          // Round 3: the wave sum of 8 of the 9 values goes through LDS instead of the register butterfly (whose
+          // permlane swaps and dependent DPP adds were 32 % of this kernel): in two passes of four values every lane
+          // stores its partial sums as rows (value, lane), lane (c = lane >> 4, s = lane & 15) adds columns
+          // 4 s .. 4 s + 3 of row c -- one conflict-free ds_read_b128 -- and four DPP adds fold the sixteen lanes of a
+          // value.  2 x (3 adds + 4 DPP) + the ninth value's six DPP adds against ~58 issue slots; the wave's own LDS
+          // accesses execute in order, so only the compiler needs the fences.  (MFMA as the summing unit was measured
+          // too: v_mfma_f32_16x16x4_f32 folds four lane rows per 32-cycle instruction -- 116 ns with one value moved to
+          // it, 159 ns with all nine, against 87 ns for the butterfly and 57 ns for this: tools/ubench/mfma_reduce.hip.)
+          float vals[9];
+#pragma unroll
+          for (int c = 0; c < 9; ++c) vals[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];
+          float x = vals[8];
+          x = gs_dpp_add_full<0x128>(x);
+          x = gs_dpp_add_full<0x124>(x);
+          x = gs_dpp_add_full<0x122>(x);
+          x = gs_dpp_add_full<0x121>(x);
+          x = gs_dpp_add_full<0x142>(x);
+          x = gs_dpp_add_full<0x143>(x);
+          if (lane == 60) s_acc[j][8] = x;
+#pragma unroll
+          for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s_tr[c * TR_STRIDE + lane] = vals[4 * pass + c];
+            __syncthreads();
+            const float4 u = *reinterpret_cast<const float4*>(s_tr + (lane >> 4) * TR_STRIDE + (lane & 15) * 4);
+            float t = (u.x + u.y) + (u.z + u.w);
+            t = gs_dpp_add_full<0xB1>(t);   // quad_perm:[1,0,3,2]
+            t = gs_dpp_add_full<0x4E>(t);   // quad_perm:[2,3,0,1]
+            t = gs_dpp_add_full<0x141>(t);  // row_half_mirror
+            t = gs_dpp_add_full<0x128>(t);  // row_ror:8: all sixteen lanes of the row hold the value's total
+            if ((lane & 15) == 0) s_acc[j][4 * pass + (lane >> 4)] = t;
+            __syncthreads();
+          }
+        } else if (GS_BWD_LDS_REDUCE == 1 && NACC == 9) {
           // Transposed through LDS instead of the register butterfly: every lane stores its 8 partial sums (row c =
           // value c, column = lane), then lane (c = lane >> 3, s = lane & 7) adds columns 8 s .. 8 s + 7 of row c and
           // three DPP adds fold the eight lanes of a value.  7 adds + 3 DPP against ~42 issue slots of swaps and DPP;
@@ -408,6 +443,10 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         }
 #pragma unroll
         for (int c = 0; c < FP; ++c) row[7 + c] = t[NS + c];
+        // the Gaussian's row index (still in this lane's register from the staging) rides in the row's last, unused
+        // word to the flush below: no index array in LDS
+        static_assert(9 + FP < ROW, "the gradient row needs a spare word");
+        row[ROW - 1] = __int_as_float(idx);
       }
       __syncthreads();  // `out` aliases the totals just read
 #pragma unroll
@@ -420,9 +459,11 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       const float val = s_out[jj][comp];
       // heuristics live at [7+F, 9+F) of the caller's row; the kernel's padded slot is 7+FP
       int dst = comp;
+      if (comp >= 9 + FP) continue;  // padding, and the index word
       if (comp >= 7 + FP) dst = comp - FP + a.F;
       else if (comp >= 7 + a.F) continue;
-      if (val != 0.0f) atomicAdd(a.grad_rows + int64_t(s_idx[jj]) * a.row_floats + dst, val);
+      if (val != 0.0f)
+        atomicAdd(a.grad_rows + int64_t(__float_as_int(s_out[jj][ROW - 1])) * a.row_floats + dst, val);
     }
     __syncthreads();
   }
@@ -432,13 +473,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[BwdShape<FP, MODE>::ARENA_F];
-  __shared__ int s_idx[64];
-#if GS_BWD_LDS_REDUCE
-  __shared__ __attribute__((aligned(16))) float s_tr_buf[8 * TR_STRIDE];
+  // transposition buffer of the lean F = 3 reduction (the only shape that uses it)
+  __shared__ __attribute__((aligned(16))) float s_tr_buf[(GS_BWD_LDS_REDUCE && FP == 3 && MODE == 0) ? TR_ROWS * TR_STRIDE : 4];
   float* s_tr = s_tr_buf;
-#else
-  float* s_tr = nullptr;
-#endif
   const int per_tile = a.sub_x * a.sub_y;
   constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
   int tile, quad;
@@ -450,7 +487,7 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
       int x0, y0, yout0;
       tile_origin(a, tile, x0, y0, yout0);
       x0 += (b & 1) * 8; y0 += ((b >> 1) & 1) * 8; yout0 += ((b >> 1) & 1) * 8;
-      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx, s_tr);
+      if (x0 < a.W && y0 < a.H) raster_bwd_body<1, FP, MODE>(a, tile, x0, y0, yout0, smem, s_tr);
       return;
     }
     const int c = b - 4 * heavy, rank = heavy + c / per_tile;
@@ -467,7 +504,7 @@ __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdA
   tile_origin(a, tile, x0, y0, yout0);
   x0 += (quad % a.sub_x) * RW; y0 += (quad / a.sub_x) * RH; yout0 += (quad / a.sub_x) * RH;
   if (x0 >= a.W || y0 >= a.H) return;
-  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, smem, s_idx, s_tr);
+  raster_bwd_body<NB, FP, MODE>(a, tile, x0, y0, yout0, smem, s_tr);
 }
 
 template <int NB, int MODE>

@@ -229,21 +229,25 @@ def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, 
     from . import parallel
     group = meta["group"]
     dev = indexes.device
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    world = dist.get_world_size(group) if dist.is_initialized() else max(parallel.EMULATED_WORLD, 1)
     M = int(touched_count)
     off = scratch_offset + nv.lib().gs_map_touched_offset(n, max(num_tiles, 1))
     touched = scratch[off:off + 4 * M].view(torch.int32)
     if meta["grad_mode"] == "sharded":
-        touched = torch.sort(touched)[0]  # rows ascend with the Gaussian index: owners become contiguous
-        chunk = -(-n // world)
-        bounds = torch.arange(world + 1, device=dev, dtype=torch.int64) * chunk
-        cuts = torch.searchsorted(indexes[touched.long()], bounds)
-        counts = (cuts[1:] - cuts[:-1]).contiguous()
+        # grouped by the rank that owns each row's Gaussian: the send groups of the all-to-all, and their sizes
+        counts = torch.empty((world,), dtype=torch.int64, device=dev)
+        grouped = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
+        cursors = torch.empty((world,), dtype=torch.int64, device=dev)
+        nv.check(nv.lib().gs_shard_group_by_owner(M, nv.ptr(touched), nv.ptr(indexes), n, world, nv.ptr(counts),
+                                                  nv.ptr(grouped), nv.ptr(cursors), world * 8, nv.stream()),
+                 "gs_shard_group_by_owner")
+        touched = grouped[:M]
     else:
         touched = touched.clone()
         counts = torch.full((1,), M, dtype=torch.int64, device=dev)
     meta["touched"] = touched
     meta["sizes"] = parallel.SizesFuture(counts, group) if world > 1 else None
+    meta["emulated_rank"] = 0 if meta.get("owned_range") is None else meta["owned_range"][0] // max(-(-n // world), 1)
 
 
 def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_var):
@@ -322,7 +326,7 @@ def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_
                      "gs_shard_pack_sparse")
             table = m["sizes"].result()
             group = m["group"]
-            rank = torch.distributed.get_rank(group)
+            rank = torch.distributed.get_rank(group) if torch.distributed.is_initialized() else m["emulated_rank"]
             if m["grad_mode"] == "sharded":   # table[q][r] = entries rank q holds for owner r
                 lists = parallel.exchange_entries_sharded(entries, [int(x) for x in table[rank]],
                                                           [int(table[q][rank]) for q in range(len(table))], group)

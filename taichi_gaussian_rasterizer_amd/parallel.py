@@ -152,6 +152,10 @@ def _reduce_partial_gradients(colour: torch.Tensor, splat: torch.Tensor, group, 
 # Exchanged bytes per rank (F = 3, 44-byte entries, M ~ V / R (1 + border) touched splats): replicated sends 44 M and
 # receives 44 (R - 1) M, sharded sends and receives 44 M (R - 1) / R, against 2 (R - 1) / R * 40 V each way for the ring
 # all-reduce of the dense rows.
+# tools/exp_shard.py only: > 1 lets ONE process run a rank's share of a sparse exchange without a process group -- the
+# pack and add kernels see lists of the size the real exchange would deliver (every peer's list taken to be as long as
+# this rank's own), nothing is communicated
+EMULATED_WORLD = 0
 EXCHANGES = ("dense", "sparse")
 GRAD_MODES = ("replicated", "sharded")
 ENTRY_HEAD = 8  # words of an entry in front of the F feature gradients: row id + 7 splat gradients
@@ -205,6 +209,9 @@ class SizesFuture:
     device synchronisation of its own."""
 
     def __init__(self, counts: torch.Tensor, group=None):
+        if EMULATED_WORLD > 1 and not dist.is_initialized():
+            self.host, self.event = torch.stack([counts] * EMULATED_WORLD).cpu(), None
+            return
         self.world = dist.get_world_size(group)
         parts, handle = exchange_sizes(counts, group, async_op=True)
         handle.wait()  # NCCL: the current stream waits; gloo: the host does
@@ -232,6 +239,8 @@ class SizesFuture:
 def exchange_entries_replicated(entries: torch.Tensor, count: int, sizes: List[int], group=None):
     """entries (>= count, W): this rank's list.  Returns [(entries of rank q, count of rank q)] for every rank, in
     rank order (padded all-gather: every rank contributes max(sizes) rows)."""
+    if EMULATED_WORLD > 1 and not dist.is_initialized():
+        return [(entries, count)] * EMULATED_WORLD
     world = dist.get_world_size(group)
     longest = max(max(sizes), 1)
     own = entries.new_empty((longest, entries.shape[1]))
@@ -244,6 +253,12 @@ def exchange_entries_replicated(entries: torch.Tensor, count: int, sizes: List[i
 def exchange_entries_sharded(entries: torch.Tensor, send_counts: List[int], recv_counts: List[int], group=None):
     """entries (sum(send_counts), W) grouped by destination rank.  Returns [(entries from rank q, count)] in rank order
     (one all-to-all with per-destination split sizes)."""
+    if EMULATED_WORLD > 1 and not dist.is_initialized():
+        at, out = 0, []
+        for q in range(EMULATED_WORLD):  # what this rank would receive: about one owner's share from every peer
+            out.append((entries[at:at + recv_counts[q]], int(recv_counts[q])))
+            at += send_counts[q]
+        return out
     world = dist.get_world_size(group)
     width = entries.shape[1]
     recv = entries.new_empty((max(sum(recv_counts), 1), width))
