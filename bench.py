@@ -95,6 +95,7 @@ def launch_command(args, port=None):
         cmd.append("--no-kernel-timing")
     if args.interleave:
         cmd += ["--interleave", str(args.interleave)]
+    cmd += ["--exchange", args.exchange, "--grad-mode", args.grad_mode]
     return cmd
 
 
@@ -109,6 +110,11 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--interleave", type=int, default=0,
                     help="N > 1: tile rows per band of the interleaved strip assignment (0 = one contiguous strip)")
+    ap.add_argument("--exchange", default="dense", choices=["dense", "sparse"],
+                    help="N > 1: how the ranks sum their partial per-Gaussian gradients (parallel.py)")
+    ap.add_argument("--grad-mode", default="replicated", choices=["replicated", "sharded"],
+                    help="N > 1: sharded = every rank ends with the gradients of its own index range only (sharded "
+                         "optimizer; implies the sparse exchange)")
     ap.add_argument("--dry-run-launch", action="store_true",
                     help="print the multi-rank launch command for --gpus N and exit")
     args = ap.parse_args()
@@ -165,8 +171,13 @@ def main():
     cfg = RasterConfig()
     g_cpu, cam_cpu = scenes.benchmark_scene(wl["n"], wl["size"], sh_degree=wl["sh_degree"], seed=0)
     g = g_cpu.to(dev)
-    if wl["backward"]:
+    owned = None
+    sharded_grads = world > 1 and args.grad_mode == "sharded" and wl["backward"]
+    if sharded_grads:
+        owned = parallel.split_owned(g, rank, world).requires_grad_(True)
+    elif wl["backward"]:
         g.requires_grad_(True)
+    grad_holder = owned if owned is not None else g
     cam = cam_cpu.to(device=dev)
     gen = torch.Generator().manual_seed(1)
     G = torch.rand(H, W, 3, generator=gen).to(dev)
@@ -176,11 +187,13 @@ def main():
 
     def step():
         if wl["backward"]:
-            for _, t in g.items():
+            for _, t in grad_holder.items():
                 t.grad = None
         if world > 1:
             r = parallel.render_gaussians_sharded(g, cam, cfg, use_sh=True, render_depth=wl["depth"],
-                                                  interleave=args.interleave)
+                                                  interleave=args.interleave, exchange=args.exchange,
+                                                  grad_mode=args.grad_mode if wl["backward"] else "replicated",
+                                                  owned=owned)
         else:
             r = gs.render_gaussians(g, cam, cfg, use_sh=True, render_depth=wl["depth"])
         info["V"] = int(r.points_in_view.shape[0])
@@ -316,6 +329,26 @@ def main():
     whole = sum(v for k, v in by.items() if k in ran)
     sv = survey_bytes(wl["n"], V, K, T, W * H, F, 3, D, wl["backward"])
 
+    # ---- the exchange step of an 8-rank frame of this workload, in bytes: exact without 8 GPUs (list lengths and V are
+    # all it depends on); the lists are measured by running the 8 ranks' forward passes one after the other here
+    exchange_model = None
+    if rank == 0 and world == 1 and wl["backward"]:
+        try:
+            model_world = 8
+            with torch.no_grad():
+                touched = [int(parallel.render_gaussians_sharded(g.detach(), cam, cfg, use_sh=True,
+                                                                 render_depth=wl["depth"], rank=q, world_size=model_world,
+                                                                 interleave=args.interleave).touched_count)
+                           for q in range(model_world)]
+            exchange_model = dict(
+                ranks=model_world, visible=V, touched_per_rank=touched, dense_rows_bytes=4 * (7 + F) * V,
+                dense=parallel.exchanged_bytes("dense", "replicated", model_world, V, touched, F),
+                sparse_replicated=parallel.exchanged_bytes("sparse", "replicated", model_world, V, touched, F),
+                sparse_sharded=parallel.exchanged_bytes("sparse", "sharded", model_world, V, touched, F),
+                note="payload bytes rank 0 sends / receives per frame; dense = ring all-reduce of the (V, 7 + F) rows")
+        except Exception as e:
+            exchange_model = dict(error=f"{type(e).__name__}: {e}")
+
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -354,9 +387,15 @@ def main():
                        "forward_cut": cfg.forward_cut,
                        "backward_from": "fixed random dL/d(outputs), no loss kernels in the timed region"
                        if wl["backward"] else None,
-                       "parallelism": "single GPU" if world == 1 else f"tile-row strips x{world} + grad all-reduce"},
+                       "parallelism": "single GPU" if world == 1 else
+                       (f"tile-row strips x{world} + " + ("grad all-reduce" if args.exchange == "dense" and
+                                                          args.grad_mode == "replicated" else
+                                                          f"sparse gradient exchange ({args.grad_mode})"))},
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "exchange": dict(mode=args.exchange if args.grad_mode == "replicated" else "sparse",
+                             grad_mode=args.grad_mode) if world > 1 else None,
+            "exchange_model_8_ranks": exchange_model,
             "whole_path": {"algorithmic_bytes_per_frame": int(whole),
                            "hbm_frac": round(whole / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                            "survey_8d_bytes_per_frame": int(sum(sv)),

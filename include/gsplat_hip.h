@@ -176,12 +176,6 @@ int gs_shard_pack_sparse(int64_t m, const int32_t* touched, int32_t num_features
                          const float* grad_rows, const float* features, float* entries, void* stream);
 int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_features, int32_t colour_col0, int64_t v,
                         float* colour_out, float* splat_out, void* stream);
-/* Sharded gradients (grad_mode "sharded"): rank r owns the Gaussians [r chunk, (r + 1) chunk), chunk = ceil(n / world).
- * Groups the m touched rows by the owner of their Gaussian (indexes (v) int64 from gs_project_fwd): grouped (m int32) =
- * the rows of owner 0, then of owner 1, ...; counts (world int64) = the group sizes, i.e. the send counts of the
- * all-to-all.  scratch: 8 bytes per rank.  world <= 64. */
-int gs_shard_group_by_owner(int64_t m, const int32_t* touched, const int64_t* indexes, int64_t n, int32_t world,
-                            int64_t* counts, int32_t* grouped, void* scratch, int64_t scratch_bytes, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,
@@ -223,6 +217,16 @@ int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const floa
  */
 int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles);
 int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles);
+/* The touched rows in ASCENDING order (the list at gs_map_touched_offset is grouped by screen region): read from the
+ * scratch gs_map_prepare has filled, written to touched_out (room for v int32; M of them are written, M = counts_host[5]).
+ * Ascending rows make the gather of gs_shard_pack_sparse and the read-modify-write of gs_shard_add_sparse walk memory
+ * forwards.  With owner_counts (world int64, optional): rank r owns the Gaussians [r chunk, (r + 1) chunk), chunk =
+ * ceil(n / world), and since rows ascend with the Gaussian index (indexes (v) int64 from gs_project_fwd) the rows of one
+ * owner are contiguous in the list -- owner_counts[r] = how many belong to owner r: the send counts of the all-to-all of
+ * grad_mode "sharded".  tmp: 4 * (ceil(v / 1024) + 1) bytes. */
+int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_tiles, const void* scratch, int64_t scratch_bytes,
+                        int32_t* touched_out, const int64_t* indexes, int64_t n, int32_t world, int64_t* owner_counts,
+                        void* tmp, int64_t tmp_bytes, void* stream);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
                    int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,

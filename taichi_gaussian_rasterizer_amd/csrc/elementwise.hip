@@ -124,47 +124,6 @@ __global__ __launch_bounds__(256) void shard_add_sparse_kernel(int64_t m, const 
   else colour[row * (F - col0) + (k - 7 - col0)] += g;
 }
 
-// Sharded gradients: the touched rows grouped by the rank that owns their Gaussian (owner = index / chunk).  Pass 1
-// counts per owner (LDS histogram, one global add per workgroup and owner); pass 2 places the rows behind per-owner
-// cursors (one returning add per workgroup and owner; the order inside a group is arbitrary and does not matter: the
-// rows of one list are distinct).
-constexpr int MAX_OWNERS = 64;
-__global__ __launch_bounds__(256) void owner_count_kernel(int64_t m, const int* touched, const int64_t* indexes,
-                                                          int64_t chunk, int world, unsigned long long* counts) {
-  __shared__ int s_cnt[MAX_OWNERS];
-  if (threadIdx.x < MAX_OWNERS) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  if (e < m) atomicAdd(&s_cnt[min(int(indexes[touched[e]] / chunk), world - 1)], 1);
-  __syncthreads();
-  if (threadIdx.x < world && s_cnt[threadIdx.x] > 0) atomicAdd(counts + threadIdx.x, (unsigned long long)s_cnt[threadIdx.x]);
-}
-
-__global__ __launch_bounds__(256) void owner_scatter_kernel(int64_t m, const int* touched, const int64_t* indexes,
-                                                            int64_t chunk, int world, const unsigned long long* counts,
-                                                            unsigned long long* cursors, int* grouped) {
-  __shared__ int s_cnt[MAX_OWNERS];
-  __shared__ long long s_base[MAX_OWNERS];
-  if (threadIdx.x < MAX_OWNERS) s_cnt[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t e = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  int owner = 0, local = 0, row = 0;
-  if (e < m) {
-    row = touched[e];
-    owner = min(int(indexes[row] / chunk), world - 1);
-    local = atomicAdd(&s_cnt[owner], 1);
-  }
-  __syncthreads();
-  if (threadIdx.x < world) {
-    long long start = 0;  // where this owner's group begins: the counts in front of it
-    for (int r = 0; r < int(threadIdx.x); ++r) start += (long long)counts[r];
-    const int c = s_cnt[threadIdx.x];
-    s_base[threadIdx.x] = start + (c > 0 ? (long long)atomicAdd(cursors + threadIdx.x, (unsigned long long)c) : 0);
-  }
-  __syncthreads();
-  if (e < m) grouped[s_base[owner] + local] = row;
-}
-
 // gradients the caller attached to the projected splats / depths themselves, added to the rasterizer's gradient rows
 __global__ __launch_bounds__(256) void rows_add_kernel(int64_t v, int row_floats, float* rows, const float* add_points,
                                                        const float* add_depth, int depth_col) {
@@ -207,31 +166,6 @@ extern "C" int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_
     hipLaunchKernelGGL(shard_add_sparse_kernel<64>, dim3(unsigned(gs_div_up(m, 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), m, entries, num_features, colour_col0, v, colour_out, splat_out);
   GS_CHECK_LAUNCH("gs_shard_add_sparse");
-  return GS_OK;
-}
-
-extern "C" int gs_shard_group_by_owner(int64_t m, const int32_t* touched, const int64_t* indexes, int64_t n,
-                                       int32_t world, int64_t* counts, int32_t* grouped, void* scratch,
-                                       int64_t scratch_bytes, void* stream) {
-  GS_REQUIRE(world >= 1 && world <= MAX_OWNERS && n >= 0, GS_ERR_INVALID_ARGUMENT,
-             "gs_shard_group_by_owner: world %d (1 .. %d)", world, MAX_OWNERS);
-  GS_REQUIRE(counts && scratch && scratch_bytes >= int64_t(world) * 8, GS_ERR_SCRATCH_TOO_SMALL,
-             "gs_shard_group_by_owner: counts / scratch (8 bytes per rank)");
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(counts, 0, size_t(world) * 8, s) != hipSuccess ||
-      hipMemsetAsync(scratch, 0, size_t(world) * 8, s) != hipSuccess) {
-    gs_set_error("gs_shard_group_by_owner: hipMemsetAsync failed");
-    return GS_ERR_LAUNCH;
-  }
-  if (m == 0) return GS_OK;
-  GS_REQUIRE(touched && indexes && grouped, GS_ERR_INVALID_ARGUMENT, "gs_shard_group_by_owner: NULL buffer");
-  const int64_t chunk = gs_div_up(n > 0 ? n : 1, world);
-  const dim3 grid(unsigned(gs_div_up(m, 256)));
-  unsigned long long* cnt = reinterpret_cast<unsigned long long*>(counts);
-  hipLaunchKernelGGL(owner_count_kernel, grid, dim3(256), 0, s, m, touched, indexes, chunk, world, cnt);
-  hipLaunchKernelGGL(owner_scatter_kernel, grid, dim3(256), 0, s, m, touched, indexes, chunk, world, cnt,
-                     static_cast<unsigned long long*>(scratch), grouped);
-  GS_CHECK_LAUNCH("gs_shard_group_by_owner");
   return GS_OK;
 }
 

@@ -321,6 +321,22 @@ struct RegionGrid {
   int row0;  // first tile row the grid covers (a contiguous shard's first row; 0 otherwise)
 };
 
+// Query cache (round 3): the binning pass evaluates the OBB query of every Gaussian anyway (to know whether it has
+// an owned tile at all); it now also runs the per-tile tests -- in index order, on rows it reads sequentially -- and
+// leaves the outcome as 16 bytes per Gaussian: the accepted tiles of the candidate span as a 64-bit mask (bit = ty *
+// span_x + tx, owned rows only) and the span itself.  The counting and the bucketing pass, which see the Gaussians in
+// REGION order, then gather those 16 bytes instead of the 28-byte row and repeat neither the query nor the tests.
+// Spans above WIDE_SPAN tiles are flagged and walked by their whole wave from the row, as before.
+struct QueryCache {
+  unsigned long long accept;
+  unsigned int x;  // min_tx (20 bits: up to 2^20 tiles) | span_x << 20
+  unsigned int y;  // min_ty (20 bits) | span_y << 20 | wide << 31
+};
+constexpr unsigned QC_WIDE = 0x80000000u;
+__device__ __forceinline__ int qc_min_tx(const QueryCache& q) { return int(q.x & 0xfffffu); }
+__device__ __forceinline__ int qc_min_ty(const QueryCache& q) { return int(q.y & 0xfffffu); }
+__device__ __forceinline__ int qc_span_x(const QueryCache& q) { return int((q.x >> 20) & 0x7fu); }
+
 __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs& a, const RegionGrid& rg) {
   const float ts = float(a.tile_size);
   int tx = int(floorf(g[0] / ts)), ty = int(floorf(g[1] / ts));
@@ -335,7 +351,7 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
 // it (and its scan) small next to the V-entry arrays.
 constexpr int BIN = 1024;
 __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
-                                                           int* part) {
+                                                           int* part, QueryCache* qcache) {
   __shared__ int s_hist[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
   __syncthreads();
@@ -348,6 +364,20 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
     const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
     const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
+    if (any) {
+      QueryCache qc;
+      qc.accept = 0ull;
+      const bool wide = q.span_x * q.span_y > WIDE_SPAN;
+      qc.x = unsigned(q.min_tx) | (wide ? 0u : unsigned(q.span_x) << 20);
+      qc.y = unsigned(q.min_ty) | (wide ? QC_WIDE : unsigned(q.span_y) << 20);
+      if (!wide) {
+        int bit = 0;
+        for (int ty = 0; ty < q.span_y; ++ty)
+          for (int tx = 0; tx < q.span_x; ++tx, ++bit)
+            if (gs_shard_owns(a.sh, ty + q.min_ty) && test_tile(q, tx, ty, a.tile_size)) qc.accept |= 1ull << bit;
+      }
+      *reinterpret_cast<uint4*>(qcache + i) = *reinterpret_cast<const uint4*>(&qc);
+    }
     if (r >= 0) atomicAdd(&s_hist[r], 1);
   }
   __syncthreads();
@@ -440,7 +470,7 @@ __device__ __forceinline__ bool locate_chunk(int block, const RegionGrid& rg, co
 // K4: per-tile histogram through the LDS window.
 __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                            const int* region_start, const int* chunk_start,
-                                                           int* tile_hist) {
+                                                           int* tile_hist, const QueryCache* qcache) {
   extern __shared__ int s_win[];  // win * win
   const int WIN = rg.win, WIN_TILES = WIN * WIN;
   int region, first, count;
@@ -459,14 +489,17 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
   bool wide = false;
   if (int(threadIdx.x) < count) {
     i = order[first + threadIdx.x];
-    const GridQuery q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
-    wide = q.span_x * q.span_y > WIDE_SPAN;
-    if (!wide)
-      for (int ty = 0; ty < q.span_y; ++ty) {
-        if (!gs_shard_owns(a.sh, ty + q.min_ty)) continue;
-        for (int tx = 0; tx < q.span_x; ++tx)
-          if (test_tile(q, tx, ty, a.tile_size)) add_tile(tx + q.min_tx, ty + q.min_ty);
+    const uint4 raw = *reinterpret_cast<const uint4*>(qcache + i);
+    const QueryCache qc = *reinterpret_cast<const QueryCache*>(&raw);
+    wide = (qc.y & QC_WIDE) != 0u;
+    if (!wide) {
+      const int min_tx = qc_min_tx(qc), min_ty = qc_min_ty(qc), span_x = qc_span_x(qc);
+      for (unsigned long long todo = qc.accept; todo != 0ull; todo &= todo - 1ull) {
+        const int bit = __ffsll(todo) - 1;
+        const int ty = bit / span_x, tx = bit - ty * span_x;
+        add_tile(tx + min_tx, ty + min_ty);  // owned rows only: the mask was built that way
       }
+    }
   }
   // Splats with a wide candidate span (hundreds of tiles for a floater that covers the screen) are walked by
   // the whole wave, 64 tiles per step: one lane looping over them alone would hold its workgroup for
@@ -496,7 +529,7 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
 // (so the OBB tests run once); splats whose candidate span exceeds 64 tiles are walked by the whole wave.
 __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                           const int* region_start, const int* chunk_start,
-                                                          int* cursors, uint64_t* pairs) {
+                                                          int* cursors, uint64_t* pairs, const QueryCache* qcache) {
   extern __shared__ int s_dyn[];  // 2 * win * win
   const int WIN = rg.win, WIN_TILES = WIN * WIN;
   int* s_cnt = s_dyn;
@@ -508,24 +541,24 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
   const int wx0 = (region % rg.regions_x) * rg.rg - RB, wy0 = (region / rg.regions_x) * rg.rg - RB + rg.row0;
   const bool active = int(threadIdx.x) < count;
   const int lane = int(threadIdx.x & 63);
-  GridQuery q;
-  q.span_x = q.span_y = 0;
-  uint64_t accept = 0ull;
+  unsigned long long accept = 0ull;
+  int min_tx = 0, min_ty = 0, span_x = 1;
   bool wide = false;  // candidate span above WIDE_SPAN tiles: walked by the whole wave in both passes
   int i = 0;
   if (active) {
     i = order[first + threadIdx.x];
-    q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
-    wide = q.span_x * q.span_y > WIDE_SPAN;
+    const uint4 raw = *reinterpret_cast<const uint4*>(qcache + i);
+    const QueryCache qc = *reinterpret_cast<const QueryCache*>(&raw);
+    wide = (qc.y & QC_WIDE) != 0u;
     if (!wide) {
-      int bit = 0;
-      for (int ty = 0; ty < q.span_y; ++ty)
-        for (int tx = 0; tx < q.span_x; ++tx, ++bit)
-          if (gs_shard_owns(a.sh, ty + q.min_ty) && test_tile(q, tx, ty, a.tile_size)) {
-            accept |= 1ull << bit;
-            const int lx = tx + q.min_tx - wx0, ly = ty + q.min_ty - wy0;
-            if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
-          }
+      accept = qc.accept;
+      min_tx = qc_min_tx(qc); min_ty = qc_min_ty(qc); span_x = qc_span_x(qc);
+      for (unsigned long long todo = accept; todo != 0ull; todo &= todo - 1ull) {
+        const int bit = __ffsll(todo) - 1;
+        const int ty = bit / span_x, tx = bit - ty * span_x;
+        const int lx = tx + min_tx - wx0, ly = ty + min_ty - wy0;
+        if (unsigned(lx) < unsigned(WIN) && unsigned(ly) < unsigned(WIN)) atomicAdd(&s_cnt[ly * WIN + lx], 1);
+      }
     }
   }
   const uint64_t wide_lanes = __ballot(wide);
@@ -568,10 +601,11 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
   };
   if (active && !wide) {
     const uint64_t pair = (uint64_t(depth_key(a.depth[i], a.depth16 != 0)) << 32) | uint64_t(uint32_t(i));
-    int bit = 0;
-    for (int ty = 0; ty < q.span_y; ++ty)
-      for (int tx = 0; tx < q.span_x; ++tx, ++bit)
-        if ((accept >> bit) & 1ull) place(tx + q.min_tx, ty + q.min_ty, pair);
+    for (unsigned long long todo = accept; todo != 0ull; todo &= todo - 1ull) {
+      const int bit = __ffsll(todo) - 1;
+      const int ty = bit / span_x, tx = bit - ty * span_x;
+      place(tx + min_tx, ty + min_ty, pair);
+    }
   }
   for (uint64_t todo = wide_lanes; todo != 0ull; todo &= todo - 1ull) {
     const int gi = __shfl(i, __ffsll(static_cast<unsigned long long>(todo)) - 1);
@@ -1087,6 +1121,7 @@ namespace {
 struct MapScratch {
   int* hist; int* cursors; int* region_of; int* order; int* region_count; int* region_start; int* part;
   int* chunk_start;
+  QueryCache* qcache;
 };
 // part[region][workgroup]; the region count is bounded by the tile count and by MAX_REGIONS
 int64_t part_entries(int64_t v, int64_t num_tiles) {
@@ -1105,6 +1140,7 @@ MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
   m.region_start = take((MAX_REGIONS + 1) * 4);
   m.chunk_start = take((MAX_REGIONS + 1) * 4);
   m.part = take(part_entries(v, num_tiles) * 4);
+  m.qcache = reinterpret_cast<QueryCache*>(take(v * int64_t(sizeof(QueryCache))));
   return m;
 }
 RegionGrid make_grid(const MapArgs& a) {
@@ -1123,12 +1159,104 @@ RegionGrid make_grid(const MapArgs& a) {
 
 extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
   return gs_align_up(num_tiles * 4, 256) * 2 + gs_align_up(v * 4, 256) * 2 +
-         gs_align_up((MAX_REGIONS + 1) * 4, 256) * 3 + gs_align_up(part_entries(v, num_tiles) * 4, 256);
+         gs_align_up((MAX_REGIONS + 1) * 4, 256) * 3 + gs_align_up(part_entries(v, num_tiles) * 4, 256) +
+         gs_align_up(v * int64_t(sizeof(QueryCache)), 256);
 }
 
 extern "C" int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles) {
   const MapScratch m = carve(nullptr, v, num_tiles);
   return reinterpret_cast<char*>(m.order) - static_cast<char*>(nullptr);
+}
+
+namespace {
+// ascending list of the rows with region_of >= 0: per-workgroup counts, then a stable compaction (every workgroup adds
+// up the counts in front of it, as the projection's compaction does)
+__global__ __launch_bounds__(1024) void touched_count_kernel(int64_t v, const int* v_dev, const int* region_of,
+                                                             int* block_counts) {
+  __shared__ int s_wave[16];
+  const int64_t live = v_dev ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
+  const int64_t i = int64_t(blockIdx.x) * 1024 + threadIdx.x;
+  const bool flag = i < live && region_of[i] >= 0;
+  const uint64_t b = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int c = 0;
+    for (int w = 0; w < 16; ++w) c += s_wave[w];
+    block_counts[blockIdx.x] = c;
+  }
+}
+
+__global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const int* v_dev, const int* region_of,
+                                                             const int* block_counts, int* touched) {
+  __shared__ int s_wave[16];
+  __shared__ int s_before[16];
+  const int64_t live = v_dev ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
+  const int64_t i = int64_t(blockIdx.x) * 1024 + threadIdx.x;
+  const bool flag = i < live && region_of[i] >= 0;
+  const uint64_t b = __ballot(flag);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) s_wave[wave] = __popcll(b);
+  int before = 0;
+  for (int j = threadIdx.x; j < int(blockIdx.x); j += 1024) before += block_counts[j];
+  for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+  if (lane == 0) s_before[wave] = before;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < 16; ++w) base += s_before[w];
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  if (flag) touched[base + __popcll(b & ((1ull << lane) - 1ull))] = int(i);
+}
+
+// owner r's share of the ascending list: [first row whose Gaussian index >= r chunk, ... (r + 1) chunk)
+__global__ void owner_cuts_kernel(const int* block_counts, int num_blocks, const int* touched, const int64_t* indexes,
+                                  int64_t chunk, int world, int64_t* owner_counts) {
+  __shared__ int64_t s_cut[65];
+  const int t = threadIdx.x;
+  int m = 0;
+  for (int j = 0; j < num_blocks; ++j) m += block_counts[j];  // every thread: a few hundred L2 reads
+  if (t <= world) {
+    const int64_t bound = int64_t(t) * chunk;
+    int lo = 0, hi = m;  // first e with indexes[touched[e]] >= bound
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (indexes[touched[mid]] < bound) lo = mid + 1; else hi = mid;
+    }
+    s_cut[t] = t == world ? m : lo;
+  }
+  __syncthreads();
+  if (t < world) owner_counts[t] = s_cut[t + 1] - s_cut[t];
+}
+}  // namespace
+
+extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_tiles, const void* scratch,
+                                   int64_t scratch_bytes, int32_t* touched_out, const int64_t* indexes, int64_t n,
+                                   int32_t world, int64_t* owner_counts, void* tmp, int64_t tmp_bytes, void* stream) {
+  GS_REQUIRE(v >= 0 && v < (int64_t(1) << 31) && num_tiles >= 1, GS_ERR_INVALID_ARGUMENT, "gs_map_touched_list: sizes");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (owner_counts) {
+    GS_REQUIRE(world >= 1 && world <= 64 && indexes && n >= 0, GS_ERR_INVALID_ARGUMENT,
+               "gs_map_touched_list: %d owners (1 .. 64) need the index list", world);
+    if (hipMemsetAsync(owner_counts, 0, size_t(world) * 8, s) != hipSuccess) {
+      gs_set_error("gs_map_touched_list: hipMemsetAsync failed");
+      return GS_ERR_LAUNCH;
+    }
+  }
+  if (v == 0) return GS_OK;
+  const int nb = int(gs_div_up(v, 1024));
+  GS_REQUIRE(scratch && scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_map_touched_list: scratch is not the one gs_map_prepare filled");
+  GS_REQUIRE(touched_out && tmp && tmp_bytes >= int64_t(nb + 1) * 4, GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_map_touched_list: NULL output or tmp < %lld bytes", (long long)(int64_t(nb + 1) * 4));
+  const MapScratch m = carve(const_cast<void*>(scratch), v, num_tiles);
+  int* block_counts = static_cast<int*>(tmp);
+  hipLaunchKernelGGL(touched_count_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts);
+  hipLaunchKernelGGL(touched_write_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts, touched_out);
+  if (owner_counts)
+    hipLaunchKernelGGL(owner_cuts_kernel, dim3(1), dim3(128), 0, s, block_counts, nb, touched_out, indexes,
+                       gs_div_up(n > 0 ? n : 1, world), world, owner_counts);
+  GS_CHECK_LAUNCH("gs_map_touched_list");
+  return GS_OK;
 }
 
 extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
@@ -1160,7 +1288,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
     const unsigned vb = unsigned(gs_div_up(v, BIN));
-    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part);
+    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part, m.qcache);
     hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
                        m.region_count, hist, num_tiles);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,
@@ -1170,7 +1298,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
     // one workgroup per chunk of <= CHUNK Gaussians of one region; surplus workgroups exit at once
     hipLaunchKernelGGL(count_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
                        size_t(rg.win) * rg.win * 4, s, a, rg, m.order,
-                       m.region_start, m.chunk_start, hist);
+                       m.region_start, m.chunk_start, hist, m.qcache);
     GS_CHECK_LAUNCH("gs_map_prepare/count");
   }
   hipLaunchKernelGGL(map_scan_kernel, dim3(tile_order ? 2 : 1), dim3(1024), 0, s, num_tiles, hist,
@@ -1202,7 +1330,7 @@ extern "C" int gs_map_finish(int64_t v, const int32_t* v_dev, int64_t k, int32_t
   // the region ordering left in scratch by gs_map_prepare is reused here
   hipLaunchKernelGGL(emit_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
                      size_t(rg.win) * rg.win * 8, s,
-                     a, rg, m.order, m.region_start, m.chunk_start, cursors, pairs);
+                     a, rg, m.order, m.region_start, m.chunk_start, cursors, pairs, m.qcache);
   GS_CHECK_LAUNCH("gs_map_finish/emit");
   const int grid = 8 * int(gs_div_up(num_tiles, 8));
   const int2* r = reinterpret_cast<const int2*>(tile_ranges);

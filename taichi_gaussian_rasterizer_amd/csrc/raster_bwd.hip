@@ -87,8 +87,16 @@ struct BwdShape {
   static constexpr int ARENA_F = (REC_F + ACC_F) > OUT_F ? (REC_F + ACC_F) : OUT_F;
 };
 
+// The wave sum of the 9 per-splat values.  0 (shipped): the transposed register butterfly.  1 / 2 (round-3 experiments,
+// kept buildable: tools/build_variant.sh lds2 raster_bwd -DGS_BWD_LDS_REDUCE=2): 8 of the values transposed through LDS
+// in one 8-row pass / two 4-row passes.  In tools/ubench/mfma_reduce.hip, beside 80 plain v_fma, the LDS form costs
+// 57 ns per call against 87 ns for the butterfly -- but in THIS kernel it is slower (0.67 vs 0.64 ms at C3, 6 waves per
+// SIMD either way): the kernel already reads three b128 records per splat from LDS, and 8 ds_write_b32 + 2 ds_read_b128
+// + 2 result writes more per (tile, splat) put the CU's LDS array at ~170 of the ~200 cycles four SIMDs spend on a
+// splat -- the reduction leaves the VALU port only to queue at the LDS.  (v1, one pass with 8 rows, also costs a wave of
+// occupancy: 1.167 vs 1.137 ms per frame.)
 #ifndef GS_BWD_LDS_REDUCE
-#define GS_BWD_LDS_REDUCE 2  // 0: register butterfly; 1: 8 values through one 8-row LDS transpose; 2: two 4-row passes
+#define GS_BWD_LDS_REDUCE 0
 #endif
 constexpr int TR_STRIDE = GS_BWD_LDS_REDUCE == 1 ? 68 : 64;  // floats per value row of the transposition buffer
 constexpr int TR_ROWS = GS_BWD_LDS_REDUCE == 1 ? 8 : 4;
@@ -321,14 +329,11 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
         // up owning value k stores it (one ds_write_b32 for all values of a chunk)
         if (GS_BWD_LDS_REDUCE == 2 && NACC == 9) {
-          // Round 3: the wave sum of 8 of the 9 values goes through LDS instead of the register butterfly (whose
-          // permlane swaps and dependent DPP adds were 32 % of this kernel): in two passes of four values every lane
-          // stores its partial sums as rows (value, lane), lane (c = lane >> 4, s = lane & 15) adds columns
-          // 4 s .. 4 s + 3 of row c -- one conflict-free ds_read_b128 -- and four DPP adds fold the sixteen lanes of a
-          // value.  2 x (3 adds + 4 DPP) + the ninth value's six DPP adds against ~58 issue slots; the wave's own LDS
-          // accesses execute in order, so only the compiler needs the fences.  (MFMA as the summing unit was measured
-          // too: v_mfma_f32_16x16x4_f32 folds four lane rows per 32-cycle instruction -- 116 ns with one value moved to
-          // it, 159 ns with all nine, against 87 ns for the butterfly and 57 ns for this: tools/ubench/mfma_reduce.hip.)
+          // experiment (see GS_BWD_LDS_REDUCE above): in two passes of four values every lane stores its partial sums
+          // as rows (value, lane), lane (c = lane >> 4, s = lane & 15) adds columns 4 s .. 4 s + 3 of row c -- one
+          // conflict-free ds_read_b128 -- and four DPP adds fold the sixteen lanes of a value.  2 x (3 adds + 4 DPP) +
+          // the ninth value's six DPP adds against ~58 issue slots; the wave's own LDS accesses execute in order, so
+          // only the compiler needs the fences.
           float vals[9];
 #pragma unroll
           for (int c = 0; c < 9; ++c) vals[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];

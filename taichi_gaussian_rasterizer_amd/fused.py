@@ -199,7 +199,10 @@ class _FusedRender(torch.autograd.Function):
                         render_depth=render_depth, group=group, shard=shard, far=float(depth_range[1]),
                         exchange=exchange, grad_mode=grad_mode, owned_range=owned_range)
         if shard is not None and exchange == "sparse":
+            ctx.meta["v_dev"] = counts
             _start_sparse_exchange(ctx.meta, n, num_tiles, host[5] if num_tiles > 0 else 0, indexes, mscratch, 0)
+        if holder is not None and shard is not None:
+            holder["touched_count"] = int(host[5]) if num_tiles > 0 else 0
         ctx.camera_grads = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])
         ctx.heur = heur
         ctx.holder = holder
@@ -231,21 +234,27 @@ def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, 
     dev = indexes.device
     world = dist.get_world_size(group) if dist.is_initialized() else max(parallel.EMULATED_WORLD, 1)
     M = int(touched_count)
-    off = scratch_offset + nv.lib().gs_map_touched_offset(n, max(num_tiles, 1))
-    touched = scratch[off:off + 4 * M].view(torch.int32)
-    if meta["grad_mode"] == "sharded":
-        # grouped by the rank that owns each row's Gaussian: the send groups of the all-to-all, and their sizes
-        counts = torch.empty((world,), dtype=torch.int64, device=dev)
-        grouped = torch.empty((max(M, 1),), dtype=torch.int32, device=dev)
-        cursors = torch.empty((world,), dtype=torch.int64, device=dev)
-        nv.check(nv.lib().gs_shard_group_by_owner(M, nv.ptr(touched), nv.ptr(indexes), n, world, nv.ptr(counts),
-                                                  nv.ptr(grouped), nv.ptr(cursors), world * 8, nv.stream()),
-                 "gs_shard_group_by_owner")
-        touched = grouped[:M]
-    else:
-        touched = touched.clone()
-        counts = torch.full((1,), M, dtype=torch.int64, device=dev)
+    lib = nv.lib()
+    sharded = meta["grad_mode"] == "sharded"
+    # the mapper's list is grouped by screen region; ascending rows (= ascending Gaussian index) make the exchange
+    # kernels walk memory forwards and put the rows of one owner rank next to each other
+    touched = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+    counts = torch.empty((world if sharded else 1,), dtype=torch.int64, device=dev)
+    tmp_bytes = 4 * (-(-n // 1024) + 1)
+    tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=dev)
+    mbytes = lib.gs_map_scratch_bytes(n, max(num_tiles, 1))
+    if num_tiles > 0 and M > 0:
+        nv.check(lib.gs_map_touched_list(n, nv.ptr(meta["v_dev"]), max(num_tiles, 1),
+                                         ctypes.c_void_p(scratch.data_ptr() + scratch_offset), mbytes, nv.ptr(touched),
+                                         nv.ptr(indexes), n, world, nv.ptr(counts) if sharded else None, nv.ptr(tmp),
+                                         tmp_bytes, nv.stream()), "gs_map_touched_list")
+    elif sharded:
+        counts.zero_()
+    if not sharded:
+        counts.fill_(M)
+    touched = touched[:M]
     meta["touched"] = touched
+    meta["touched_count"] = M
     meta["sizes"] = parallel.SizesFuture(counts, group) if world > 1 else None
     meta["emulated_rank"] = 0 if meta.get("owned_range") is None else meta["owned_range"][0] // max(-(-n // world), 1)
 
@@ -546,8 +555,11 @@ class _FrameRender(torch.autograd.Function):
                         exchange=exchange, grad_mode=grad_mode, owned_range=owned_range)
         if shard is not None and exchange == "sparse":
             T_tiles = L.tiles_x * L.tiles_y
+            ctx.meta["v_dev"] = ws.view(torch.int32).as_strided((8,), (1,), L.counts // 4)
             _start_sparse_exchange(ctx.meta, n, T_tiles, host[5] if T_tiles > 0 else 0,
                                    ws.view(torch.int64).as_strided((n,), (1,), L.indexes // 8), scratch, L.s_stage)
+        if holder is not None and shard is not None:
+            holder["touched_count"] = int(host[5]) if L.tiles_x * L.tiles_y > 0 else 0
         ctx.camera_grads = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])
         ctx.frame, ctx.layout = frame, L
         ctx.heur = heur
@@ -753,8 +765,11 @@ def render_fused(gaussians, camera_params, config: RasterConfig, render_depth: b
     indexes._gs_unique = True
     if not render_depth:
         img_depth = img_var = None
-    return Rendering(image=image, image_weight=alpha, depth=img_depth, depth_var=img_var,
-                     median_depth=median if render_median_depth else None, camera=camera_params, config=config,
-                     point_visibility=vis if config.compute_visibility else None,
-                     point_heuristic=heur if config.compute_point_heuristic else None,
-                     points_in_view=indexes, point_depth=depths, gaussians2d=g2d)
+    rendering = Rendering(image=image, image_weight=alpha, depth=img_depth, depth_var=img_var,
+                          median_depth=median if render_median_depth else None, camera=camera_params, config=config,
+                          point_visibility=vis if config.compute_visibility else None,
+                          point_heuristic=heur if config.compute_point_heuristic else None,
+                          points_in_view=indexes, point_depth=depths, gaussians2d=g2d)
+    if shard is not None:  # how many splats can reach this rank's rows (= its list in a sparse exchange)
+        object.__setattr__(rendering, "touched_count", holder.get("touched_count"))
+    return rendering

@@ -3,8 +3,13 @@
 stage=$1; shift
 for round in 1 2 3; do
   for lib in "$@"; do
-    GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 2>/dev/null | python3 -c "
-import sys, json; d = json.loads(sys.stdin.read()); s = d['stages_ms_untimed_pass']
-print('$lib', d['ms_per_step'], '$stage', s.get('$stage'))"
+    GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 2>gpurun_out/ab_err.txt | python3 -c "
+import sys, json
+text = sys.stdin.read()
+try:
+    d = json.loads(text); s = d['stages_ms_untimed_pass']
+    print('$lib', d['ms_per_step'], '$stage', s.get('$stage'))
+except Exception as e:
+    print('$lib', 'bench failed:', open('gpurun_out/ab_err.txt').read()[-300:])"
   done
 done
