@@ -388,11 +388,21 @@ typedef struct GsFrameLayout {
   int32_t num_features, grad_row_floats, tiles_x, tiles_y, local_height;
 } GsFrameLayout;
 
+/* Optional fork of gs_frame_fwd (host struct of caller-owned handles, NULL = everything on `stream`): the colour stage
+ * (SH evaluation / feature gather) is enqueued on side_stream (a hipStream_t) between fork_event and join_event (two
+ * hipEvent_t), i.e. underneath the tile mapper, and the rasterizer waits for it.  Everything is ordered behind `stream`
+ * again when the call's work has run: buffers need no other synchronisation than for the unforked call. */
+typedef struct GsFrameFork {
+  void* side_stream;
+  void* fork_event;
+  void* join_event;
+} GsFrameFork;
+
 int gs_frame_layout(const GsFrame* frame, GsFrameLayout* layout);
 int gs_frame_fwd(const GsFrame* frame, const float* position, const float* log_scaling, const float* rotation,
                  const float* alpha_logit, const float* feature, const float* T_camera_world, const float* projection,
                  void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, int32_t* counts_host,
-                 void* counts_event, void* stream);
+                 void* counts_event, const GsFrameFork* fork, void* stream);
 int gs_frame_bwd(const GsFrame* frame, const float* position, const float* log_scaling, const float* rotation,
                  const float* alpha_logit, const float* feature, const float* T_camera_world, const float* projection,
                  void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, int64_t v, int64_t k,

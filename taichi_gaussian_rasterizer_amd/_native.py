@@ -43,6 +43,11 @@ class GsFrame(ctypes.Structure):
                 ("depth_forward_cut", c_float)]
 
 
+class GsFrameFork(ctypes.Structure):
+    """include/gsplat_hip.h GsFrameFork: side stream + two events for the colour stage of gs_frame_fwd"""
+    _fields_ = [("side_stream", c_void_p), ("fork_event", c_void_p), ("join_event", c_void_p)]
+
+
 class GsFrameLayout(ctypes.Structure):
     """include/gsplat_hip.h GsFrameLayout: byte offsets of the frame's sub-buffers (-1 = absent)"""
     _OFFSETS = ("workspace_bytes", "fwd_scratch_bytes", "bwd_scratch_bytes", "stage_bytes",
@@ -115,7 +120,8 @@ SIGNATURES = {
     "gs_depth_split_fwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P]),
     "gs_depth_split_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "gs_frame_layout": (ctypes.c_int, [_FRAME, POINTER(GsFrameLayout)]),
-    "gs_frame_fwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _P]),
+    "gs_frame_fwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P,
+                                     POINTER(GsFrameFork), _P]),
     "gs_frame_bwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _P,
                                      _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }

@@ -124,7 +124,8 @@ extern "C" int gs_frame_layout(const GsFrame* f, GsFrameLayout* out) {
 extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float* log_scaling, const float* rotation,
                             const float* alpha_logit, const float* feature, const float* T_camera_world,
                             const float* projection, void* workspace, int64_t workspace_bytes, void* scratch,
-                            int64_t scratch_bytes, int32_t* counts_host, void* counts_event, void* stream) {
+                            int64_t scratch_bytes, int32_t* counts_host, void* counts_event, const GsFrameFork* fork,
+                            void* stream) {
   Dims d;
   if (int rc = frame_dims(f, &d)) return rc;
   GsFrameLayout L;
@@ -166,13 +167,32 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   const int32_t* v_dev = counts;
   float* colours = feats + d.col0;
   int rc;
+  // The colours are needed by the rasterizer only, and the tile mapper -- a chain of short, latency-bound launches -- does
+  // not need them: with a fork the colour kernel (HBM-bound) runs on the caller's side stream underneath the mapper and
+  // joins in front of the rasterizer.  Two event records and two stream waits, all issued from this call.
+  const bool forked = fork && fork->side_stream && fork->fork_event && fork->join_event && d.T > 0;
+  void* colour_stream = stream;
+  if (forked) {
+    if (hipEventRecord(static_cast<hipEvent_t>(fork->fork_event), s) != hipSuccess ||
+        hipStreamWaitEvent(static_cast<hipStream_t>(fork->side_stream), static_cast<hipEvent_t>(fork->fork_event), 0) !=
+            hipSuccess) {
+      gs_set_error("gs_frame_fwd: fork onto the side stream failed");
+      return GS_ERR_LAUNCH;
+    }
+    colour_stream = fork->side_stream;
+  }
   if (f->sh_degree >= 0 && shard)
     rc = gs_sh_fwd_shard(d.n, v_dev, d.C, f->sh_degree, feature, position, indexes, cam_pos, points, f->height, cfg,
-                         shard, colours, d.F, stream);
+                         shard, colours, d.F, colour_stream);
   else if (f->sh_degree >= 0)
-    rc = gs_sh_fwd(d.n, v_dev, d.C, f->sh_degree, feature, position, indexes, cam_pos, colours, d.F, stream);
+    rc = gs_sh_fwd(d.n, v_dev, d.C, f->sh_degree, feature, position, indexes, cam_pos, colours, d.F, colour_stream);
   else
-    rc = gs_feature_gather_fwd(d.n, v_dev, d.C, feature, indexes, colours, d.F, stream);
+    rc = gs_feature_gather_fwd(d.n, v_dev, d.C, feature, indexes, colours, d.F, colour_stream);
+  if (forked && hipEventRecord(static_cast<hipEvent_t>(fork->join_event),
+                               static_cast<hipStream_t>(fork->side_stream)) != hipSuccess) {
+    gs_set_error("gs_frame_fwd: join event record failed");
+    return GS_ERR_LAUNCH;
+  }
   if (rc) return rc;
   if (vis && hipMemsetAsync(vis, 0, size_t(d.n) * 4, s) != hipSuccess) {
     gs_set_error("gs_frame_fwd: hipMemsetAsync failed");
@@ -209,6 +229,10 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
                           tile_ranges, o2p, nullptr, at<char>(scratch, L.s_pairs), shard, stage, L.stage_bytes,
                           stream)))
     return rc;
+  if (forked && hipStreamWaitEvent(s, static_cast<hipEvent_t>(fork->join_event), 0) != hipSuccess) {
+    gs_set_error("gs_frame_fwd: join onto the main stream failed");
+    return GS_ERR_LAUNCH;
+  }
   if ((rc = gs_raster_fwd(d.n, d.F, points, feats, tile_ranges, o2p, f->k_capacity, f->width, f->height, &rcfg,
                           tile_order, counts + 7, image, alpha, vis, shard, stream)))
     return rc;

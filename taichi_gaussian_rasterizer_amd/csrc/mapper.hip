@@ -321,12 +321,13 @@ struct RegionGrid {
   int row0;  // first tile row the grid covers (a contiguous shard's first row; 0 otherwise)
 };
 
-// Query cache (round 3): the binning pass evaluates the OBB query of every Gaussian anyway (to know whether it has
-// an owned tile at all); it now also runs the per-tile tests -- in index order, on rows it reads sequentially -- and
-// leaves the outcome as 16 bytes per Gaussian: the accepted tiles of the candidate span as a 64-bit mask (bit = ty *
-// span_x + tx, owned rows only) and the span itself.  The counting and the bucketing pass, which see the Gaussians in
-// REGION order, then gather those 16 bytes instead of the 28-byte row and repeat neither the query nor the tests.
-// Spans above WIDE_SPAN tiles are flagged and walked by their whole wave from the row, as before.
+// Query cache (round 3): the counting pass leaves the outcome of its OBB query and per-tile tests as 16 bytes per
+// Gaussian, in the REGION order it works in: the accepted tiles of the candidate span as a 64-bit mask (bit = ty *
+// span_x + tx, owned rows only) and the span itself.  The bucketing pass, which walks the same order, reads those 16
+// bytes sequentially instead of gathering the 28-byte row again and repeating the query and the tests (emit 48 -> 34 us
+// at C3).  Spans above WIDE_SPAN tiles are flagged and walked by their whole wave from the row, as before.
+// (Filling the cache in the binning pass instead, in index order, made that pass 23 us slower and the two consumers
+// gather it at random: 7 us worse in all.)
 struct QueryCache {
   unsigned long long accept;
   unsigned int x;  // min_tx (20 bits: up to 2^20 tiles) | span_x << 20
@@ -351,7 +352,7 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
 // it (and its scan) small next to the V-entry arrays.
 constexpr int BIN = 1024;
 __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
-                                                           int* part, QueryCache* qcache) {
+                                                           int* part) {
   __shared__ int s_hist[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
   __syncthreads();
@@ -364,20 +365,6 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
     const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
     const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
-    if (any) {
-      QueryCache qc;
-      qc.accept = 0ull;
-      const bool wide = q.span_x * q.span_y > WIDE_SPAN;
-      qc.x = unsigned(q.min_tx) | (wide ? 0u : unsigned(q.span_x) << 20);
-      qc.y = unsigned(q.min_ty) | (wide ? QC_WIDE : unsigned(q.span_y) << 20);
-      if (!wide) {
-        int bit = 0;
-        for (int ty = 0; ty < q.span_y; ++ty)
-          for (int tx = 0; tx < q.span_x; ++tx, ++bit)
-            if (gs_shard_owns(a.sh, ty + q.min_ty) && test_tile(q, tx, ty, a.tile_size)) qc.accept |= 1ull << bit;
-      }
-      *reinterpret_cast<uint4*>(qcache + i) = *reinterpret_cast<const uint4*>(&qc);
-    }
     if (r >= 0) atomicAdd(&s_hist[r], 1);
   }
   __syncthreads();
@@ -470,7 +457,7 @@ __device__ __forceinline__ bool locate_chunk(int block, const RegionGrid& rg, co
 // K4: per-tile histogram through the LDS window.
 __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGrid rg, const int* order,
                                                            const int* region_start, const int* chunk_start,
-                                                           int* tile_hist, const QueryCache* qcache) {
+                                                           int* tile_hist, QueryCache* qcache) {
   extern __shared__ int s_win[];  // win * win
   const int WIN = rg.win, WIN_TILES = WIN * WIN;
   int region, first, count;
@@ -489,17 +476,23 @@ __global__ __launch_bounds__(CHUNK) void count_binned_kernel(MapArgs a, RegionGr
   bool wide = false;
   if (int(threadIdx.x) < count) {
     i = order[first + threadIdx.x];
-    const uint4 raw = *reinterpret_cast<const uint4*>(qcache + i);
-    const QueryCache qc = *reinterpret_cast<const QueryCache*>(&raw);
-    wide = (qc.y & QC_WIDE) != 0u;
+    const GridQuery q = grid_query(a.points + 7 * int64_t(i), a.Wp, a.Hp, a.tile_size, a.thr);
+    wide = q.span_x * q.span_y > WIDE_SPAN;
+    QueryCache qc;
+    qc.accept = 0ull;
+    qc.x = unsigned(q.min_tx) | (wide ? 0u : unsigned(q.span_x) << 20);
+    qc.y = unsigned(q.min_ty) | (wide ? QC_WIDE : unsigned(q.span_y) << 20);
     if (!wide) {
-      const int min_tx = qc_min_tx(qc), min_ty = qc_min_ty(qc), span_x = qc_span_x(qc);
-      for (unsigned long long todo = qc.accept; todo != 0ull; todo &= todo - 1ull) {
-        const int bit = __ffsll(todo) - 1;
-        const int ty = bit / span_x, tx = bit - ty * span_x;
-        add_tile(tx + min_tx, ty + min_ty);  // owned rows only: the mask was built that way
-      }
+      int bit = 0;
+      for (int ty = 0; ty < q.span_y; ++ty)
+        for (int tx = 0; tx < q.span_x; ++tx, ++bit)
+          if (gs_shard_owns(a.sh, ty + q.min_ty) && test_tile(q, tx, ty, a.tile_size)) {
+            qc.accept |= 1ull << bit;
+            add_tile(tx + q.min_tx, ty + q.min_ty);
+          }
     }
+    // by position in the region order: the bucketing pass reads it back with consecutive 16-byte loads
+    *reinterpret_cast<uint4*>(qcache + first + threadIdx.x) = *reinterpret_cast<const uint4*>(&qc);
   }
   // Splats with a wide candidate span (hundreds of tiles for a floater that covers the screen) are walked by
   // the whole wave, 64 tiles per step: one lane looping over them alone would hold its workgroup for
@@ -547,7 +540,7 @@ __global__ __launch_bounds__(CHUNK) void emit_binned_kernel(MapArgs a, RegionGri
   int i = 0;
   if (active) {
     i = order[first + threadIdx.x];
-    const uint4 raw = *reinterpret_cast<const uint4*>(qcache + i);
+    const uint4 raw = *reinterpret_cast<const uint4*>(qcache + first + threadIdx.x);
     const QueryCache qc = *reinterpret_cast<const QueryCache*>(&raw);
     wide = (qc.y & QC_WIDE) != 0u;
     if (!wide) {
@@ -1212,9 +1205,14 @@ __global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const in
 __global__ void owner_cuts_kernel(const int* block_counts, int num_blocks, const int* touched, const int64_t* indexes,
                                   int64_t chunk, int world, int64_t* owner_counts) {
   __shared__ int64_t s_cut[65];
+  __shared__ int s_part[128];
   const int t = threadIdx.x;
+  int part = 0;
+  for (int j = t; j < num_blocks; j += 128) part += block_counts[j];
+  s_part[t] = part;
+  __syncthreads();
   int m = 0;
-  for (int j = 0; j < num_blocks; ++j) m += block_counts[j];  // every thread: a few hundred L2 reads
+  for (int j = 0; j < 128; ++j) m += s_part[j];
   if (t <= world) {
     const int64_t bound = int64_t(t) * chunk;
     int lo = 0, hi = m;  // first e with indexes[touched[e]] >= bound
@@ -1288,7 +1286,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
     const unsigned vb = unsigned(gs_div_up(v, BIN));
-    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part, m.qcache);
+    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part);
     hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
                        m.region_count, hist, num_tiles);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,

@@ -169,15 +169,22 @@ __global__ __launch_bounds__(256) void sh_fwd_staged_kernel(int64_t v, const int
   const bool evaluate = live && (touch.points2d == nullptr || sh_touched(touch, i));
   const int idx = evaluate ? int(indexes[i]) : -1;  // n < 2^31
   float* tile = s_tile[wave];
+  // three phases, each over all 12 pieces: every load of the wave is in flight before the first LDS store waits for one
+  int src[12];
+  float4 piece[12];
+#pragma unroll
+  for (int k = 0; k < 12; ++k) src[k] = __shfl(idx, (k * 64 + lane) / 12);
+#pragma unroll
+  for (int k = 0; k < 12; ++k) {
+    const int e = k * 64 + lane;
+    piece[k] = src[k] >= 0 ? reinterpret_cast<const float4*>(params + int64_t(src[k]) * ROW)[e - (e / 12) * 12]
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int k = 0; k < 12; ++k) {
     const int e = k * 64 + lane;
     const int r = e / 12, q = e - r * 12;
-    const int src = __shfl(idx, r);
-    if (src >= 0) {
-      const float4 piece = reinterpret_cast<const float4*>(params + int64_t(src) * ROW)[q];
-      *reinterpret_cast<float4*>(tile + r * TILE_STRIDE + q * 4) = piece;
-    }
+    *reinterpret_cast<float4*>(tile + r * TILE_STRIDE + q * 4) = piece[k];
   }
   __syncthreads();
   if (!live) return;

@@ -476,6 +476,25 @@ def _counts_event(dev: torch.device):
     return ring["evs"][ring["at"]]
 
 
+_FORKS = {}    # device index -> (side stream, events, GsFrameFork)
+# gs_frame_fwd runs the colour stage on a side stream underneath the tile mapper (GS_FORK_COLOURS=0: developer A/B)
+FORK_COLOURS = __import__("os").environ.get("GS_FORK_COLOURS", "1") != "0"
+
+
+def _frame_fork(dev: torch.device):
+    hit = _FORKS.get(dev.index)
+    if hit is None:
+        side = torch.cuda.Stream(device=dev)
+        evs = []
+        for _ in range(2):
+            ev = torch.cuda.Event()
+            ev.record()  # materialises the hipEvent_t
+            evs.append(ev)
+        fork = nv.GsFrameFork(side.cuda_stream, evs[0].cuda_event, evs[1].cuda_event)
+        hit = _FORKS[dev.index] = (side, evs, fork)
+    return ctypes.byref(hit[2])
+
+
 def _empty(dev, shape):
     key = (dev, shape)
     t = _EMPTY.get(key)
@@ -513,7 +532,8 @@ class _FrameRender(torch.autograd.Function):
         nv.check(lib.gs_frame_fwd(ctypes.byref(frame), nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation),
                                   nv.ptr(alpha_logit), nv.ptr(feature), nv.ptr(T), nv.ptr(proj), nv.ptr(ws),
                                   L.workspace_bytes, nv.ptr(scratch), L.fwd_scratch_bytes, nv.ptr(host_counts),
-                                  ready_handle, nv.stream()), "gs_frame_fwd")
+                                  ready_handle, _frame_fork(dev) if FORK_COLOURS else None, nv.stream()),
+                 "gs_frame_fwd")
         ready.synchronize()  # waits for the mapper's scan only, not for the rasterizer
         host = host_counts.tolist()
         K, max_tile, overflow, V = host[0], host[1], host[2], host[4]
