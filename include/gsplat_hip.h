@@ -176,6 +176,14 @@ int gs_shard_pack_sparse(int64_t m, const int32_t* touched, int32_t num_features
                          const float* grad_rows, const float* features, float* entries, void* stream);
 int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_features, int32_t colour_col0, int64_t v,
                         float* colour_out, float* splat_out, void* stream);
+/* All `world` lists at once, for lists whose row ids ASCEND (gs_map_touched_list): entries_host / counts_host are HOST
+ * arrays of `world` device pointers / entry counts (padding beyond a list's count is not read).  One pass: every row of
+ * colour_out / splat_out is WRITTEN (zeros where no list has it -- the buffers need not be cleared), the lists are
+ * summed in rank order inside each 256-row tile, so every rank gets the same bits, as with gs_shard_add_sparse list by
+ * list.  tmp: 4 * world * (ceil(v / 256) + 1) bytes. */
+int gs_shard_merge_sparse(int32_t world, const float* const* entries_host, const int64_t* counts_host,
+                          int32_t num_features, int32_t colour_col0, int64_t v, float* colour_out, float* splat_out,
+                          void* tmp, int64_t tmp_bytes, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,

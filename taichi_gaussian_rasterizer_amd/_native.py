@@ -92,6 +92,7 @@ SIGNATURES = {
     "gs_map_touched_offset": (_I64, [_I64, _I64]),
     "gs_shard_pack_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P]),
     "gs_shard_add_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _I64, _P, _P, _P]),
+    "gs_shard_merge_sparse": (ctypes.c_int, [_I32, _P, _P, _I32, _I32, _I64, _P, _P, _P, _I64, _P]),
     "gs_map_touched_list": (ctypes.c_int, [_I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _P, _P, _I64, _P]),
     "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _SHARD, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,

@@ -124,6 +124,64 @@ __global__ __launch_bounds__(256) void shard_add_sparse_kernel(int64_t m, const 
   else colour[row * (F - col0) + (k - 7 - col0)] += g;
 }
 
+// All lists of a sparse exchange merged in ONE pass over the dense rows (lists with ascending row ids): adding list
+// after list touches every cache line of the dense buffers once per list -- a list holds every world-th row, so its
+// 28-byte pieces land in every 128-byte line -- i.e. `world` read-modify-write passes over (V, 7 + F) floats.  Here a
+// workgroup owns MERGE_ROWS consecutive rows: it finds its slice of every list (precomputed cuts), sums the slices into
+// an LDS tile list by list in rank order (the rows of one list are distinct: plain adds, a barrier between lists --
+// every rank computes the same sums bit for bit) and writes the tile: every dense row is written exactly once, zeros
+// included, so the caller does not clear the buffers either.
+constexpr int MERGE_ROWS = 256, MERGE_MAX_LISTS = 64;
+struct MergeLists {
+  const float* entries[MERGE_MAX_LISTS];
+  long long count[MERGE_MAX_LISTS];
+};
+
+__global__ __launch_bounds__(256) void sparse_cuts_kernel(MergeLists lists, int world, int width, int num_blocks,
+                                                          int* cuts) {
+  const int64_t t = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  const int q = int(t / (num_blocks + 1)), b = int(t - int64_t(q) * (num_blocks + 1));
+  if (q >= world) return;
+  const int bound = b * MERGE_ROWS;
+  const float* e = lists.entries[q];
+  long long lo = 0, hi = lists.count[q];  // first entry whose row id >= bound
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (__float_as_int(e[mid * width]) < bound) lo = mid + 1; else hi = mid;
+  }
+  cuts[int64_t(q) * (num_blocks + 1) + b] = int(lo);
+}
+
+__global__ __launch_bounds__(256) void sparse_merge_kernel(MergeLists lists, int world, int F, int col0, int64_t v,
+                                                           int num_blocks, const int* cuts, float* colour,
+                                                           float* splat) {
+  extern __shared__ float s_rows[];  // MERGE_ROWS x (7 + F)
+  const int width = 8 + F, cols = 7 + F;
+  const int64_t row0 = int64_t(blockIdx.x) * MERGE_ROWS;
+  for (int e = threadIdx.x; e < MERGE_ROWS * cols; e += 256) s_rows[e] = 0.0f;
+  __syncthreads();
+  const int sub = threadIdx.x >> 4, c = threadIdx.x & 15;  // 16 lanes per entry, 16 entries per step
+  for (int q = 0; q < world; ++q) {
+    const int lo = cuts[int64_t(q) * (num_blocks + 1) + blockIdx.x], hi = cuts[int64_t(q) * (num_blocks + 1) + blockIdx.x + 1];
+    const float* e = lists.entries[q];
+    for (int i = lo + sub; i < hi; i += 16) {
+      const int row = __float_as_int(e[int64_t(i) * width]) - int(row0);
+      for (int k = c; k < cols; k += 16) s_rows[row * cols + k] += e[int64_t(i) * width + 1 + k];
+    }
+    __syncthreads();
+  }
+  const int64_t rows = v - row0 < MERGE_ROWS ? v - row0 : MERGE_ROWS;
+  const int sc = 7 + col0, cc = F - col0;
+  for (int e = threadIdx.x; e < rows * sc; e += 256) {
+    const int r = e / sc, k = e - r * sc;
+    splat[row0 * sc + e] = s_rows[r * cols + k];
+  }
+  for (int e = threadIdx.x; e < rows * cc; e += 256) {
+    const int r = e / cc, k = e - r * cc;
+    colour[row0 * cc + e] = s_rows[r * cols + sc + k];
+  }
+}
+
 // gradients the caller attached to the projected splats / depths themselves, added to the rasterizer's gradient rows
 __global__ __launch_bounds__(256) void rows_add_kernel(int64_t v, int row_floats, float* rows, const float* add_points,
                                                        const float* add_depth, int depth_col) {
@@ -166,6 +224,36 @@ extern "C" int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_
     hipLaunchKernelGGL(shard_add_sparse_kernel<64>, dim3(unsigned(gs_div_up(m, 4))), dim3(256), 0,
                        static_cast<hipStream_t>(stream), m, entries, num_features, colour_col0, v, colour_out, splat_out);
   GS_CHECK_LAUNCH("gs_shard_add_sparse");
+  return GS_OK;
+}
+
+extern "C" int gs_shard_merge_sparse(int32_t world, const float* const* entries_host, const int64_t* counts_host,
+                                     int32_t num_features, int32_t colour_col0, int64_t v, float* colour_out,
+                                     float* splat_out, void* tmp, int64_t tmp_bytes, void* stream) {
+  GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES && colour_col0 >= 0 && colour_col0 < num_features,
+             GS_ERR_INVALID_ARGUMENT, "gs_shard_merge_sparse: %d features, colours from column %d", num_features,
+             colour_col0);
+  GS_REQUIRE(world >= 1 && world <= MERGE_MAX_LISTS && entries_host && counts_host, GS_ERR_INVALID_ARGUMENT,
+             "gs_shard_merge_sparse: %d lists (1 .. %d)", world, MERGE_MAX_LISTS);
+  if (v == 0) return GS_OK;
+  GS_REQUIRE(colour_out && splat_out, GS_ERR_INVALID_ARGUMENT, "gs_shard_merge_sparse: NULL output");
+  const int nb = int(gs_div_up(v, MERGE_ROWS));
+  GS_REQUIRE(tmp && tmp_bytes >= int64_t(world) * (nb + 1) * 4, GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_shard_merge_sparse: tmp %lld < %lld bytes", (long long)tmp_bytes, (long long)(int64_t(world) * (nb + 1) * 4));
+  MergeLists lists;
+  for (int q = 0; q < world; ++q) {
+    GS_REQUIRE(counts_host[q] == 0 || entries_host[q], GS_ERR_INVALID_ARGUMENT, "gs_shard_merge_sparse: list %d is NULL", q);
+    lists.entries[q] = entries_host[q];
+    lists.count[q] = counts_host[q];
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* cuts = static_cast<int*>(tmp);
+  const int64_t searches = int64_t(world) * (nb + 1);
+  hipLaunchKernelGGL(sparse_cuts_kernel, dim3(unsigned(gs_div_up(searches, 256))), dim3(256), 0, s, lists, world,
+                     8 + num_features, nb, cuts);
+  hipLaunchKernelGGL(sparse_merge_kernel, dim3(nb), dim3(256), size_t(MERGE_ROWS) * (7 + num_features) * 4, s, lists,
+                     world, num_features, colour_col0, v, nb, cuts, colour_out, splat_out);
+  GS_CHECK_LAUNCH("gs_shard_merge_sparse");
   return GS_OK;
 }
 

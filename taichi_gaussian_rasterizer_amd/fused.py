@@ -342,11 +342,17 @@ def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_
             else:                             # table[q][0] = list length of rank q
                 lists = parallel.exchange_entries_replicated(entries, M, [int(t[0]) for t in table], group)
             m["exchanged"] = dict(width=width, own=M, table=table)
-            pf = torch.zeros((rows_n, C), dtype=torch.float32, device=dev)
-            pp = torch.zeros((rows_n, 7 + col0), dtype=torch.float32, device=dev)
-            for ent, cnt in lists:  # one list after the other, in rank order: the same sums on every rank
-                nv.check(lib.gs_shard_add_sparse(cnt, nv.ptr(ent), F, col0, rows_n, nv.ptr(pf), nv.ptr(pp), s),
-                         "gs_shard_add_sparse")
+            # every list in one pass over the dense rows (rank order inside each tile: the same sums on every rank;
+            # every row is written, so no clearing)
+            pf = torch.empty((rows_n, C), dtype=torch.float32, device=dev)
+            pp = torch.empty((rows_n, 7 + col0), dtype=torch.float32, device=dev)
+            nl = len(lists)
+            ptrs = (ctypes.c_void_p * nl)(*[ent.data_ptr() if cnt else None for ent, cnt in lists])
+            cnts = (ctypes.c_int64 * nl)(*[cnt for _, cnt in lists])
+            tmp_bytes = 4 * nl * (-(-rows_n // 256) + 1)
+            tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=dev)
+            nv.check(lib.gs_shard_merge_sparse(nl, ptrs, cnts, F, col0, rows_n, nv.ptr(pf), nv.ptr(pp), nv.ptr(tmp),
+                                               tmp_bytes, s), "gs_shard_merge_sparse")
             g_feat, g_feat_stride = nv.ptr(pf), C
             g_pts, g_pts_stride = pp, 7 + col0
         elif m["shard"] is not None:

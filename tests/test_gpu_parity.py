@@ -127,6 +127,61 @@ def test_device_sqrt_and_log_are_the_host_ones_bit_for_bit():
     assert (pu.to_np(l_out)[sub_].view(np.uint32) == ref.view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("F,col0,world,v", [(3, 0, 8, 100_000), (5, 2, 3, 777), (12, 0, 64, 5000), (3, 0, 1, 300)])
+def test_sparse_exchange_kernels(F, col0, world, v):
+    """the three kernels of the sharded frame's sparse exchange against numpy: gs_shard_pack_sparse (entries [row, 7 + F
+    words], colour gradients of clamped channels zeroed), gs_shard_add_sparse (one list into the dense rows) and
+    gs_shard_merge_sparse (all lists in one pass) -- the latter two must agree BIT FOR BIT (same summation order)"""
+    import ctypes
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    lib = nv.lib()
+    rng = np.random.default_rng(F * 100 + world)
+    RS = lib.gs_grad_row_floats(F)
+    W = 8 + F
+    lists, counts = [], []
+    for q in range(world):
+        m = int(rng.integers(0, max(v // max(world // 2, 1), 2)))
+        rows = np.sort(rng.choice(v, size=min(m, v), replace=False)).astype(np.int32)
+        grad = rng.standard_normal((v, RS)).astype(np.float32)
+        feats = rng.random((v, F)).astype(np.float32)
+        feats[rng.random((v, F)) < 0.2] = 1.0          # clamped channels
+        ent = torch.empty((max(rows.shape[0], 1) + 3, W), dtype=torch.float32, device=DEV)  # + padding rows
+        ent.view(torch.int32)[:, 0] = -1
+        nv.check(lib.gs_shard_pack_sparse(rows.shape[0], nv.ptr(dev(rows)), F, col0, nv.ptr(dev(grad)),
+                                          nv.ptr(dev(feats)), nv.ptr(ent), nv.stream()), "gs_shard_pack_sparse")
+        want = np.concatenate([rows.view(np.float32)[:, None], grad[rows, :7 + F]], 1)
+        mask = ~((feats[rows] > 0) & (feats[rows] < 1))
+        mask[:, :col0] = False
+        want[:, 8:][mask] = 0.0
+        got = pu.to_np(ent)[:rows.shape[0]]
+        assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"pack of list {q}"
+        lists.append(ent)
+        counts.append(int(rows.shape[0]))
+    # list by list
+    pf = torch.zeros((v, F - col0), device=DEV)
+    pp = torch.zeros((v, 7 + col0), device=DEV)
+    for ent, cnt in zip(lists, counts):
+        nv.check(lib.gs_shard_add_sparse(cnt + 3, nv.ptr(ent), F, col0, v, nv.ptr(pf), nv.ptr(pp), nv.stream()),
+                 "gs_shard_add_sparse")   # the padding rows (id -1) are skipped
+    ref_p, ref_f = np.zeros((v, 7 + col0), np.float32), np.zeros((v, F - col0), np.float32)
+    for ent, cnt in zip(lists, counts):
+        e = pu.to_np(ent)[:cnt]
+        ids = e[:, 0].view(np.int32)
+        ref_p[ids] += e[:, 1:8 + col0]
+        ref_f[ids] += e[:, 8 + col0:]
+    assert (pu.to_np(pp) == ref_p).all() and (pu.to_np(pf) == ref_f).all()
+    # all at once: every row written (the buffers start as garbage), same bits
+    mf = torch.full((v, F - col0), float("nan"), device=DEV)
+    mp_ = torch.full((v, 7 + col0), float("nan"), device=DEV)
+    ptrs = (ctypes.c_void_p * world)(*[e.data_ptr() for e in lists])
+    cnts = (ctypes.c_int64 * world)(*counts)
+    tmp_bytes = 4 * world * (-(-v // 256) + 1)
+    tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=DEV)
+    nv.check(lib.gs_shard_merge_sparse(world, ptrs, cnts, F, col0, v, nv.ptr(mf), nv.ptr(mp_), nv.ptr(tmp), tmp_bytes,
+                                       nv.stream()), "gs_shard_merge_sparse")
+    assert torch.equal(mp_, pp) and torch.equal(mf, pf)
+
+
 def test_hip_lib_cumsum_and_sort():
     rng = np.random.default_rng(0)
     for n in (1, 2, 1023, 1024, 1025, 100000, 1 << 20):
