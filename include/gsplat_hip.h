@@ -231,10 +231,10 @@ int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles);
  * forwards.  With owner_counts (world int64, optional): rank r owns the Gaussians [r chunk, (r + 1) chunk), chunk =
  * ceil(n / world), and since rows ascend with the Gaussian index (indexes (v) int64 from gs_project_fwd) the rows of one
  * owner are contiguous in the list -- owner_counts[r] = how many belong to owner r: the send counts of the all-to-all of
- * grad_mode "sharded".  tmp: 4 * (ceil(v / 1024) + 1) bytes. */
+ * grad_mode "sharded". */
 int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_tiles, const void* scratch, int64_t scratch_bytes,
                         int32_t* touched_out, const int64_t* indexes, int64_t n, int32_t world, int64_t* owner_counts,
-                        void* tmp, int64_t tmp_bytes, void* stream);
+                        void* stream);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
                    int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,
@@ -406,18 +406,25 @@ typedef struct GsFrameFork {
   void* join_event;
 } GsFrameFork;
 
+/* Optional per-stage timing of the frame calls: stage_events is a HOST array of 2 * GS_FWD_STAGES (gs_frame_fwd) or
+ * 2 * GS_BWD_STAGES (gs_frame_bwd) hipEvent_t handles; entry 2 k is recorded in front of stage k and 2 k + 1 behind it, on
+ * the stream the stage runs on; NULL entries (or a NULL array) are skipped.  This is how a caller measures one kernel's
+ * launch time with HIP events on the launch stream although the whole direction is one call (bench.py's roofline). */
+enum { GS_FWD_PROJECT = 0, GS_FWD_COLOURS, GS_FWD_MAP_PREPARE, GS_FWD_MAP_FINISH, GS_FWD_RASTER, GS_FWD_STAGES };
+enum { GS_BWD_RASTER = 0, GS_BWD_COLOURS, GS_BWD_PROJECT, GS_BWD_STAGES };
+
 int gs_frame_layout(const GsFrame* frame, GsFrameLayout* layout);
 int gs_frame_fwd(const GsFrame* frame, const float* position, const float* log_scaling, const float* rotation,
                  const float* alpha_logit, const float* feature, const float* T_camera_world, const float* projection,
                  void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, int32_t* counts_host,
-                 void* counts_event, const GsFrameFork* fork, void* stream);
+                 void* counts_event, const GsFrameFork* fork, void* const* stage_events, void* stream);
 int gs_frame_bwd(const GsFrame* frame, const float* position, const float* log_scaling, const float* rotation,
                  const float* alpha_logit, const float* feature, const float* T_camera_world, const float* projection,
                  void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, int64_t v, int64_t k,
                  const float* grad_image, const float* grad_img_depth, const float* grad_img_var,
                  const float* attached_points, const float* attached_depth, float* d_position, float* d_log_scaling,
                  float* d_rotation, float* d_alpha_logit, float* d_feature, float* d_T_camera_world,
-                 float* d_projection, float* d_camera_centre, void* stream);
+                 float* d_projection, float* d_camera_centre, void* const* stage_events, void* stream);
 
 /* ------------------------------------------------------------------- Morton ordering --
  * replaces: misc/morton_sort.py:78-88 code_points64_kernel (Grid.morton_code64, :37-66).  points (n,3);

@@ -93,7 +93,7 @@ SIGNATURES = {
     "gs_shard_pack_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P]),
     "gs_shard_add_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _I64, _P, _P, _P]),
     "gs_shard_merge_sparse": (ctypes.c_int, [_I32, _P, _P, _I32, _I32, _I64, _P, _P, _P, _I64, _P]),
-    "gs_map_touched_list": (ctypes.c_int, [_I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _P, _P, _I64, _P]),
+    "gs_map_touched_list": (ctypes.c_int, [_I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _P, _P]),
     "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _SHARD, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,
                                       _P, _I64, _P]),
@@ -122,9 +122,9 @@ SIGNATURES = {
     "gs_depth_split_bwd": (ctypes.c_int, [_I64, _I32, _P, _P, c_float, _P, _P, _P, _P, _P]),
     "gs_frame_layout": (ctypes.c_int, [_FRAME, POINTER(GsFrameLayout)]),
     "gs_frame_fwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _P, _P,
-                                     POINTER(GsFrameFork), _P]),
+                                     POINTER(GsFrameFork), _P, _P]),
     "gs_frame_bwd": (ctypes.c_int, [_FRAME, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I64, _I64, _P, _P, _P,
-                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+                                     _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None
@@ -149,6 +149,30 @@ class KernelTimer:
 
 timer = KernelTimer()
 
+# stages of gs_frame_fwd / gs_frame_bwd (include/gsplat_hip.h GS_FWD_* / GS_BWD_*), under the names of the entry points
+# they stand for, so that bench.py's per-stage table and byte formulas read the same either way
+FRAME_FWD_STAGES = ("gs_project_fwd", "gs_sh_fwd", "gs_map_prepare", "gs_map_finish", "gs_raster_fwd")
+FRAME_BWD_STAGES = ("gs_raster_bwd", "gs_sh_bwd", "gs_project_bwd")
+
+
+def stage_events(names):
+    """None, or a ctypes array of hipEvent_t pairs for the stages of a frame call that `timer` is asked to time; the
+    (start, stop) torch events are filed under the stage names in `timer.records`."""
+    if not timer.enabled:
+        return None
+    arr = (c_void_p * (2 * len(names)))()
+    used = False
+    for k, name in enumerate(names):
+        if timer.only is not None and name not in timer.only:
+            continue
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        b.record()  # creates the hipEvent_t handles the library records again around the stage
+        arr[2 * k], arr[2 * k + 1] = a.cuda_event, b.cuda_event
+        timer.records.setdefault(name, []).append((a, b))
+        used = True
+    return arr if used else None
+
 
 class _TimedLib:
     """Attribute access returns the ctypes function; launches are bracketed by events when
@@ -159,7 +183,8 @@ class _TimedLib:
 
     def __getattr__(self, name):  # first lookup only: the result is stored on the instance
         fn = getattr(self._h, name)
-        if name.endswith("_bytes") or name in ("gs_last_error", "gs_version", "gs_grad_row_floats"):
+        if name.endswith("_bytes") or name in ("gs_last_error", "gs_version", "gs_grad_row_floats", "gs_frame_layout",
+                                               "gs_frame_fwd", "gs_frame_bwd", "gs_map_touched_offset"):
             setattr(self, name, fn)
             return fn
 

@@ -60,6 +60,19 @@ int frame_dims(const GsFrame* f, Dims* d) {
 template <typename T>
 T* at(void* base, int64_t off) { return reinterpret_cast<T*>(static_cast<char*>(base) + off); }
 
+// optional per-stage timing: events[2 k] / events[2 k + 1] are recorded on `stream` in front of / behind stage k
+struct StageTimer {
+  void* const* events;
+  int rc = GS_OK;
+  void mark(int stage, int end, void* stream) {
+    if (!events || !events[2 * stage + end]) return;
+    if (hipEventRecord(static_cast<hipEvent_t>(events[2 * stage + end]), static_cast<hipStream_t>(stream)) != hipSuccess) {
+      gs_set_error("frame: hipEventRecord of a stage timer failed");
+      rc = GS_ERR_LAUNCH;
+    }
+  }
+};
+
 }  // namespace
 
 int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling, const float* rotation,
@@ -125,7 +138,8 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
                             const float* alpha_logit, const float* feature, const float* T_camera_world,
                             const float* projection, void* workspace, int64_t workspace_bytes, void* scratch,
                             int64_t scratch_bytes, int32_t* counts_host, void* counts_event, const GsFrameFork* fork,
-                            void* stream) {
+                            void* const* stage_events, void* stream) {
+  StageTimer tm{stage_events};
   Dims d;
   if (int rc = frame_dims(f, &d)) return rc;
   GsFrameLayout L;
@@ -158,12 +172,14 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   float* ndc = at<float>(scratch, L.s_ndc_depth);
   void* stage = at<char>(scratch, L.s_stage);
 
+  tm.mark(GS_FWD_PROJECT, 0, stream);
   if (int rc = gs_project_fwd_ex(d.n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
                                  f->width, f->height, f->near_plane, f->far_plane, cfg, points, depth, ndc, indexes,
                                  slot_of, counts, f->render_depth ? feats : nullptr, d.F, cam_pos, stage,
                                  L.stage_bytes, L.grad_rows >= 0 ? at<float>(workspace, L.grad_rows) : nullptr, d.RS,
                                  stream))
     return rc;
+  tm.mark(GS_FWD_PROJECT, 1, stream);
   const int32_t* v_dev = counts;
   float* colours = feats + d.col0;
   int rc;
@@ -181,6 +197,7 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     }
     colour_stream = fork->side_stream;
   }
+  tm.mark(GS_FWD_COLOURS, 0, colour_stream);
   if (f->sh_degree >= 0 && shard)
     rc = gs_sh_fwd_shard(d.n, v_dev, d.C, f->sh_degree, feature, position, indexes, cam_pos, points, f->height, cfg,
                          shard, colours, d.F, colour_stream);
@@ -188,6 +205,7 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     rc = gs_sh_fwd(d.n, v_dev, d.C, f->sh_degree, feature, position, indexes, cam_pos, colours, d.F, colour_stream);
   else
     rc = gs_feature_gather_fwd(d.n, v_dev, d.C, feature, indexes, colours, d.F, colour_stream);
+  tm.mark(GS_FWD_COLOURS, 1, colour_stream);
   if (forked && hipEventRecord(static_cast<hipEvent_t>(fork->join_event),
                                static_cast<hipStream_t>(fork->side_stream)) != hipSuccess) {
     gs_set_error("gs_frame_fwd: join event record failed");
@@ -215,9 +233,11 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     }
     return GS_OK;
   }
+  tm.mark(GS_FWD_MAP_PREPARE, 0, stream);
   if ((rc = gs_map_prepare(d.n, v_dev, points, f->width, f->height, cfg, f->k_capacity, tile_ranges, counts + 4,
                            counts_host, tile_order, shard, stage, L.stage_bytes, stream)))
     return rc;
+  tm.mark(GS_FWD_MAP_PREPARE, 1, stream);
   // K, the overflow flag and V are final here and the scan kernel has stored them into the pinned host words itself:
   // the host waits on this event while the sort and the rasterizer are still running
   if (counts_event && hipEventRecord(static_cast<hipEvent_t>(counts_event), s) != hipSuccess) {
@@ -225,17 +245,21 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     return GS_ERR_LAUNCH;
   }
   const int32_t tile_hint = f->max_tile_hint > 0 ? -f->max_tile_hint : 0;  // a sizing hint: fuller tiles are still sorted
+  tm.mark(GS_FWD_MAP_FINISH, 0, stream);
   if ((rc = gs_map_finish(d.n, v_dev, f->k_capacity, tile_hint, points, ndc, f->width, f->height, cfg, f->use_depth16,
                           tile_ranges, o2p, nullptr, at<char>(scratch, L.s_pairs), shard, stage, L.stage_bytes,
                           stream)))
     return rc;
+  tm.mark(GS_FWD_MAP_FINISH, 1, stream);
   if (forked && hipStreamWaitEvent(s, static_cast<hipEvent_t>(fork->join_event), 0) != hipSuccess) {
     gs_set_error("gs_frame_fwd: join onto the main stream failed");
     return GS_ERR_LAUNCH;
   }
+  tm.mark(GS_FWD_RASTER, 0, stream);
   if ((rc = gs_raster_fwd(d.n, d.F, points, feats, tile_ranges, o2p, f->k_capacity, f->width, f->height, &rcfg,
                           tile_order, counts + 7, image, alpha, vis, shard, stream)))
     return rc;
+  tm.mark(GS_FWD_RASTER, 1, stream);
   if (f->render_depth &&
       (rc = gs_depth_split_fwd(d.P, d.C, image, alpha, 1e-6f, at<float>(workspace, L.out_image),
                                at<float>(workspace, L.img_depth), at<float>(workspace, L.img_var), stream)))
@@ -253,7 +277,7 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
                             at<float>(scratch, L.s_median_cover), nullptr, shard, stream)))
       return rc;
   }
-  return GS_OK;
+  return tm.rc;
 }
 
 int gs_rows_add(int64_t v, int32_t row_floats, float* rows, const float* add_points, const float* add_depth,
@@ -266,7 +290,8 @@ extern "C" int gs_frame_bwd(const GsFrame* f, const float* position, const float
                             const float* grad_img_depth, const float* grad_img_var, const float* attached_points,
                             const float* attached_depth, float* d_position, float* d_log_scaling, float* d_rotation,
                             float* d_alpha_logit, float* d_feature, float* d_T_camera_world, float* d_projection,
-                            float* d_camera_centre, void* stream) {
+                            float* d_camera_centre, void* const* stage_events, void* stream) {
+  StageTimer tm{stage_events};
   Dims d;
   if (int rc = frame_dims(f, &d)) return rc;
   GsFrameLayout L;
@@ -305,12 +330,14 @@ extern "C" int gs_frame_bwd(const GsFrame* f, const float* position, const float
       return rc;
     g_img = assembled;
   }
+  tm.mark(GS_BWD_RASTER, 0, stream);
   if (g_img && v > 0 && d.P > 0 && k > 0 &&
       (rc = gs_raster_bwd(v, d.F, points, feats, at<int32_t>(workspace, L.tile_ranges),
                           at<int32_t>(workspace, L.overlap_to_point), k, f->width, f->height, cfg,
                           at<int32_t>(workspace, L.tile_order), counts + 7, at<float>(workspace, L.image), g_img, rows,
                           nullptr, stream)))
     return rc;
+  tm.mark(GS_BWD_RASTER, 1, stream);
   // gradients a caller attached to the projected splats / depths themselves (e.g. a regulariser)
   const float* extra_depth = nullptr;
   if (v > 0 && (attached_points || (attached_depth && f->render_depth))) {
@@ -318,18 +345,23 @@ extern "C" int gs_frame_bwd(const GsFrame* f, const float* position, const float
       return rc;
   }
   if (attached_depth && v > 0 && !f->render_depth) extra_depth = attached_depth;
+  tm.mark(GS_BWD_COLOURS, 0, stream);
   if (f->sh_degree >= 0)
     rc = gs_sh_bwd(d.n, v, d.C, f->sh_degree, feature, position, indexes, 1, slot_of, cam_pos, rows + 7 + d.col0, d.RS,
                    feats + d.col0, d.F, d_feature, nullptr, d_camera_centre, stream);
   else
     rc = gs_feature_gather_bwd(d.n, d.C, slot_of, rows + 7 + d.col0, d.RS, d_feature, stream);
+  tm.mark(GS_BWD_COLOURS, 1, stream);
   if (rc) return rc;
   const bool camera = d_T_camera_world || d_projection;
   const float* gd = f->render_depth ? rows + 7 : extra_depth;
   const float* gd2 = f->render_depth ? rows + 8 : nullptr;
-  return gs_project_bwd(d.n, v, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, f->width,
-                        f->height, cfg, slot_of, rows, d.RS, gd, gd2, f->render_depth ? d.RS : 1, d_position,
-                        d_log_scaling, d_rotation, d_alpha_logit, d_T_camera_world, d_projection,
-                        camera ? at<char>(scratch, L.b_camera) : nullptr,
-                        camera ? gs_project_bwd_scratch_bytes(d.n) : 0, stream);
+  tm.mark(GS_BWD_PROJECT, 0, stream);
+  rc = gs_project_bwd(d.n, v, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, f->width,
+                      f->height, cfg, slot_of, rows, d.RS, gd, gd2, f->render_depth ? d.RS : 1, d_position,
+                      d_log_scaling, d_rotation, d_alpha_logit, d_T_camera_world, d_projection,
+                      camera ? at<char>(scratch, L.b_camera) : nullptr,
+                      camera ? gs_project_bwd_scratch_bytes(d.n) : 0, stream);
+  tm.mark(GS_BWD_PROJECT, 1, stream);
+  return rc ? rc : tm.rc;
 }

@@ -352,11 +352,12 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
 // it (and its scan) small next to the V-entry arrays.
 constexpr int BIN = 1024;
 __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
-                                                           int* part) {
+                                                           int* part, int* touched_blocks) {
   __shared__ int s_hist[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
+  bool mine = false;
   if (i < live_count(a)) {
     // Gaussians whose candidate span is empty (off-screen within the cull margin; above or below this rank's
     // strip when the frame is sharded) are left out of the ordering, so the counting and bucketing passes never
@@ -366,8 +367,11 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
     const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
     if (r >= 0) atomicAdd(&s_hist[r], 1);
+    mine = r >= 0;
   }
-  __syncthreads();
+  // how many of this workgroup's rows are in the ordering at all (gs_map_touched_list compacts them in ascending order)
+  const int touched = __syncthreads_count(mine);
+  if (threadIdx.x == 0) touched_blocks[blockIdx.x] = touched;
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
 }
 
@@ -1115,6 +1119,7 @@ struct MapScratch {
   int* hist; int* cursors; int* region_of; int* order; int* region_count; int* region_start; int* part;
   int* chunk_start;
   QueryCache* qcache;
+  int* touched_blocks;  // per 1024-row workgroup of the binning pass: rows that entered the ordering
 };
 // part[region][workgroup]; the region count is bounded by the tile count and by MAX_REGIONS
 int64_t part_entries(int64_t v, int64_t num_tiles) {
@@ -1134,6 +1139,7 @@ MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
   m.chunk_start = take((MAX_REGIONS + 1) * 4);
   m.part = take(part_entries(v, num_tiles) * 4);
   m.qcache = reinterpret_cast<QueryCache*>(take(v * int64_t(sizeof(QueryCache))));
+  m.touched_blocks = take((gs_div_up(v > 0 ? v : 1, BIN) + 1) * 4);
   return m;
 }
 RegionGrid make_grid(const MapArgs& a) {
@@ -1153,7 +1159,7 @@ RegionGrid make_grid(const MapArgs& a) {
 extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
   return gs_align_up(num_tiles * 4, 256) * 2 + gs_align_up(v * 4, 256) * 2 +
          gs_align_up((MAX_REGIONS + 1) * 4, 256) * 3 + gs_align_up(part_entries(v, num_tiles) * 4, 256) +
-         gs_align_up(v * int64_t(sizeof(QueryCache)), 256);
+         gs_align_up(v * int64_t(sizeof(QueryCache)), 256) + gs_align_up((gs_div_up(v > 0 ? v : 1, BIN) + 1) * 4, 256);
 }
 
 extern "C" int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles) {
@@ -1162,24 +1168,8 @@ extern "C" int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles) {
 }
 
 namespace {
-// ascending list of the rows with region_of >= 0: per-workgroup counts, then a stable compaction (every workgroup adds
-// up the counts in front of it, as the projection's compaction does)
-__global__ __launch_bounds__(1024) void touched_count_kernel(int64_t v, const int* v_dev, const int* region_of,
-                                                             int* block_counts) {
-  __shared__ int s_wave[16];
-  const int64_t live = v_dev ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
-  const int64_t i = int64_t(blockIdx.x) * 1024 + threadIdx.x;
-  const bool flag = i < live && region_of[i] >= 0;
-  const uint64_t b = __ballot(flag);
-  if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = __popcll(b);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    int c = 0;
-    for (int w = 0; w < 16; ++w) c += s_wave[w];
-    block_counts[blockIdx.x] = c;
-  }
-}
-
+// ascending list of the rows with region_of >= 0: a stable compaction on the per-workgroup counts the binning pass
+// left (every workgroup adds up the counts in front of it, as the projection's compaction does)
 __global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const int* v_dev, const int* region_of,
                                                              const int* block_counts, int* touched) {
   __shared__ int s_wave[16];
@@ -1229,7 +1219,7 @@ __global__ void owner_cuts_kernel(const int* block_counts, int num_blocks, const
 
 extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_tiles, const void* scratch,
                                    int64_t scratch_bytes, int32_t* touched_out, const int64_t* indexes, int64_t n,
-                                   int32_t world, int64_t* owner_counts, void* tmp, int64_t tmp_bytes, void* stream) {
+                                   int32_t world, int64_t* owner_counts, void* stream) {
   GS_REQUIRE(v >= 0 && v < (int64_t(1) << 31) && num_tiles >= 1, GS_ERR_INVALID_ARGUMENT, "gs_map_touched_list: sizes");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (owner_counts) {
@@ -1244,11 +1234,9 @@ extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_
   const int nb = int(gs_div_up(v, 1024));
   GS_REQUIRE(scratch && scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
              "gs_map_touched_list: scratch is not the one gs_map_prepare filled");
-  GS_REQUIRE(touched_out && tmp && tmp_bytes >= int64_t(nb + 1) * 4, GS_ERR_SCRATCH_TOO_SMALL,
-             "gs_map_touched_list: NULL output or tmp < %lld bytes", (long long)(int64_t(nb + 1) * 4));
+  GS_REQUIRE(touched_out, GS_ERR_INVALID_ARGUMENT, "gs_map_touched_list: touched_out is NULL");
   const MapScratch m = carve(const_cast<void*>(scratch), v, num_tiles);
-  int* block_counts = static_cast<int*>(tmp);
-  hipLaunchKernelGGL(touched_count_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts);
+  const int* block_counts = m.touched_blocks;  // BIN = 1024 rows per workgroup of the binning pass
   hipLaunchKernelGGL(touched_write_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts, touched_out);
   if (owner_counts)
     hipLaunchKernelGGL(owner_cuts_kernel, dim3(1), dim3(128), 0, s, block_counts, nb, touched_out, indexes,
@@ -1286,7 +1274,7 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
     const unsigned vb = unsigned(gs_div_up(v, BIN));
-    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part);
+    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part, m.touched_blocks);
     hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
                        m.region_count, hist, num_tiles);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,

@@ -147,70 +147,10 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev
   }
 }
 
-// RGB at degree 3 (48 floats = 192 bytes of coefficients per Gaussian), round 3: the coefficient rows of a wave's 64
-// Gaussians are fetched as ONE virtual 12-KiB array -- lane l of load k takes the 16-byte piece k * 64 + l, i.e. piece
-// (k * 64 + l) % 12 of row (k * 64 + l) / 12 -- so that consecutive lanes read consecutive pieces of the same row
-// (a lane loading its own row touches 64 different lines per instruction: 4.1 TB/s; the dense adjoint, which writes its
-// rows through the same kind of LDS tile, runs at the copy rate).  The rows land in LDS with a 52-float stride (conflict
-// free for the b128 reads back: 52 l mod 64 hits 16 distinct 4-word groups per 16 lanes).
-#ifndef GS_SH_STAGED_FWD
-#define GS_SH_STAGED_FWD 1
-#endif
-__global__ __launch_bounds__(256) void sh_fwd_staged_kernel(int64_t v, const int* v_dev, const float* params,
-                                                            const float* positions, const int64_t* indexes,
-                                                            const float* cam, float* out, int out_stride,
-                                                            const ShTouch touch) {
-  constexpr int D = 16, ROW = 48, TILE_STRIDE = 52;
-  __shared__ __attribute__((aligned(16))) float s_tile[4][64 * TILE_STRIDE];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
-  const int64_t live_n = v_dev != nullptr ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
-  const bool live = i < live_n;
-  const bool evaluate = live && (touch.points2d == nullptr || sh_touched(touch, i));
-  const int idx = evaluate ? int(indexes[i]) : -1;  // n < 2^31
-  float* tile = s_tile[wave];
-  // three phases, each over all 12 pieces: every load of the wave is in flight before the first LDS store waits for one
-  int src[12];
-  float4 piece[12];
-#pragma unroll
-  for (int k = 0; k < 12; ++k) src[k] = __shfl(idx, (k * 64 + lane) / 12);
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const int e = k * 64 + lane;
-    piece[k] = src[k] >= 0 ? reinterpret_cast<const float4*>(params + int64_t(src[k]) * ROW)[e - (e / 12) * 12]
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-#pragma unroll
-  for (int k = 0; k < 12; ++k) {
-    const int e = k * 64 + lane;
-    const int r = e / 12, q = e - r * 12;
-    *reinterpret_cast<float4*>(tile + r * TILE_STRIDE + q * 4) = piece[k];
-  }
-  __syncthreads();
-  if (!live) return;
-  if (!evaluate) {
-    // never rasterized here; 0.5 = "not clamped" for gs_sh_bwd's mask (see sh_fwd_kernel)
-    for (int c = 0; c < 3; ++c) out[i * out_stride + c] = 0.5f;
-    return;
-  }
-  const float dx = positions[3 * int64_t(idx)] - cam[0], dy = positions[3 * int64_t(idx) + 1] - cam[1],
-              dz = positions[3 * int64_t(idx) + 2] - cam[2];
-  const float nrm = sqrtf(dx * dx + dy * dy + dz * dz);
-  float Y[D];
-  rsh<3>(dx / nrm, dy / nrm, dz / nrm, Y);
-  const float4* mine = reinterpret_cast<const float4*>(tile + lane * TILE_STRIDE);
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    float acc = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float4 t = mine[c * 4 + k];
-      // the same summation order as sh_fwd_kernel (d ascending): bit-identical colours
-      acc += Y[4 * k] * t.x; acc += Y[4 * k + 1] * t.y; acc += Y[4 * k + 2] * t.z; acc += Y[4 * k + 3] * t.w;
-    }
-    out[i * out_stride + c] = fminf(fmaxf(acc + 0.5f, 0.0f), 1.0f);
-  }
-}
+// Measured in round 3 and not kept: the RGB / degree-3 forward with the coefficient rows of a wave fetched as one
+// virtual 12-KiB array (lane l of load k takes 16-byte piece k * 64 + l: consecutive lanes read consecutive pieces of a
+// row) into an LDS tile, as the dense adjoint writes its rows -- bit-identical colours, 46.4 us against 48.0 us for the
+// lane-per-row loads above (189 MB either way, 4.1 TB/s): the forward is not bound by how its loads coalesce.
 
 template <int DEG, bool UNIQUE>
 __global__ __launch_bounds__(256) void sh_bwd_kernel(int64_t v, int C, const float* params, const float* positions,
@@ -413,12 +353,6 @@ int sh_fwd_launch(int64_t v, const int32_t* v_dev, int32_t channels, int32_t deg
 #define SH_FWD(DEG)                                                                                               \
   if (channels == 3) SH_FWD_C(DEG, 3);                                                                            \
   else SH_FWD_C(DEG, 0)
-  if (GS_SH_STAGED_FWD && degree == 3 && channels == 3) {
-    hipLaunchKernelGGL(sh_fwd_staged_kernel, grid, block, 0, s, v, v_dev, params, positions, indexes, camera_pos, out,
-                       out_stride, touch);
-    GS_CHECK_LAUNCH(who);
-    return GS_OK;
-  }
   switch (degree) {
     case 0: SH_FWD(0); break;
     case 1: SH_FWD(1); break;

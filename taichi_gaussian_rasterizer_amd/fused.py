@@ -240,14 +240,12 @@ def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, 
     # kernels walk memory forwards and put the rows of one owner rank next to each other
     touched = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
     counts = torch.empty((world if sharded else 1,), dtype=torch.int64, device=dev)
-    tmp_bytes = 4 * (-(-n // 1024) + 1)
-    tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=dev)
     mbytes = lib.gs_map_scratch_bytes(n, max(num_tiles, 1))
     if num_tiles > 0 and M > 0:
         nv.check(lib.gs_map_touched_list(n, nv.ptr(meta["v_dev"]), max(num_tiles, 1),
                                          ctypes.c_void_p(scratch.data_ptr() + scratch_offset), mbytes, nv.ptr(touched),
-                                         nv.ptr(indexes), n, world, nv.ptr(counts) if sharded else None, nv.ptr(tmp),
-                                         tmp_bytes, nv.stream()), "gs_map_touched_list")
+                                         nv.ptr(indexes), n, world, nv.ptr(counts) if sharded else None, nv.stream()),
+                 "gs_map_touched_list")
     elif sharded:
         counts.zero_()
     if not sharded:
@@ -538,8 +536,8 @@ class _FrameRender(torch.autograd.Function):
         nv.check(lib.gs_frame_fwd(ctypes.byref(frame), nv.ptr(position), nv.ptr(log_scaling), nv.ptr(rotation),
                                   nv.ptr(alpha_logit), nv.ptr(feature), nv.ptr(T), nv.ptr(proj), nv.ptr(ws),
                                   L.workspace_bytes, nv.ptr(scratch), L.fwd_scratch_bytes, nv.ptr(host_counts),
-                                  ready_handle, _frame_fork(dev) if FORK_COLOURS else None, nv.stream()),
-                 "gs_frame_fwd")
+                                  ready_handle, _frame_fork(dev) if FORK_COLOURS else None,
+                                  nv.stage_events(nv.FRAME_FWD_STAGES), nv.stream()), "gs_frame_fwd")
         ready.synchronize()  # waits for the mapper's scan only, not for the rasterizer
         host = host_counts.tolist()
         K, max_tile, overflow, V = host[0], host[1], host[2], host[4]
@@ -667,7 +665,7 @@ class _FrameRender(torch.autograd.Function):
                                   L.workspace_bytes, nv.ptr(scratch), L.bwd_scratch_bytes, V, K, nv.ptr(gi),
                                   nv.ptr(gd_), nv.ptr(gv_), nv.ptr(att_p), nv.ptr(att_d), nv.ptr(d_pos), nv.ptr(d_ls),
                                   nv.ptr(d_rot), nv.ptr(d_al), nv.ptr(d_feature), nv.ptr(d_T), nv.ptr(d_proj),
-                                  nv.ptr(d_centre), nv.stream()), "gs_frame_bwd")
+                                  nv.ptr(d_centre), nv.stage_events(nv.FRAME_BWD_STAGES), nv.stream()), "gs_frame_bwd")
         if config.compute_point_heuristic and V > 0:
             ctx.heur.copy_(rows[:V, 7 + F:9 + F])
         # publish the rasterizer's part of dL/d(gaussians2d) (see _FusedRender.backward)

@@ -153,7 +153,7 @@ def test_frame_layout_is_computed_on_the_host():
     # the calls themselves check the buffers before any launch
     f = frame()
     rc = lib.gs_frame_fwd(ctypes.byref(f), None, None, None, None, None, None, None, None, 0, None, 0, None, None, None,
-                          None)
+                          None, None)
     assert rc == -4 and b"workspace" in lib.gs_last_error()
-    rc = lib.gs_frame_bwd(ctypes.byref(sh), *([None] * 7), None, 0, None, 0, 0, 0, *([None] * 13), None)
+    rc = lib.gs_frame_bwd(ctypes.byref(sh), *([None] * 7), None, 0, None, 0, 0, 0, *([None] * 13), None, None)
     assert rc == -2 and b"sharded" in lib.gs_last_error()
