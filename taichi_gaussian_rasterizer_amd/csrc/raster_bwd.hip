@@ -66,6 +66,16 @@ __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, f
   ds_dsig = ds_dx * -z;
 }
 
+// The antialiased pdf's sigmoid S(z) = 1 / (1 + exp(-(1.6 z + 0.07 z^3))) (taichi_lib/generic.py:341-369) and its
+// derivative in 14 issue slots: a = S(z), d = dS/dz = (1.6 + 0.21 z^2) S (1 - S), with S (1 - S) = e a^2 for e =
+// exp(-(...)) (no 1 - S, the log2(e) factors folded into the polynomial).
+__device__ __forceinline__ void s_sig_parts(float z, float& a, float& d) {
+  const float z2 = z * z;
+  const float e = gs_exp2_fast(z * __builtin_fmaf(-0.07f * 1.44269504088896341f, z2, -1.6f * 1.44269504088896341f));
+  a = gs_rcp_fast(1.0f + e);
+  d = __builtin_fmaf(0.21f, z2, 1.6f) * (e * a * a);
+}
+
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 1  // minimum waves per SIMD requested from the register allocator (1 = no constraint)
 #endif
@@ -192,9 +202,16 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         const float r2 = __log2f(al * a.inv_thr) * (FULL ? 1.38629436111989f : 1.0f);
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, r2, float(x0) + 0.5f - mx, float(y0) + 0.5f - my);
       }
-      s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
-      // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
-      s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
+      if (FULL && a.aa) {
+        // antialiased pdf: the per-pixel code works in the splat's frame (ux, uy) and needs the sigmas and the half
+        // pixel in sigma units, not the scaled ellipse frame
+        s_geo[lane][0] = make_float4(mx, my, p[4], p[5]);
+        s_geo[lane][1] = make_float4(0.5f * isx, 0.5f * isy, al, __int_as_float(mask));
+      } else {
+        s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+        // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
+        s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
+      }
       if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
       const float* f = a.features + int64_t(idx) * a.F;
 #pragma unroll
@@ -237,25 +254,33 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         const float dx = Xf[b] - g0v.x, dy = Yf[b] - g0v.y;
         float p, tx = 0, ty = 0;
         float dmx = 0, dmy = 0, dax = 0, day = 0, dsx = 0, dsy = 0;
+        float Px = 0, Py = 0;  // antialias: d pdf / d (ux, uy), the splat-frame gradient the mean and axis terms share
         if (FULL && a.aa) {
-          // taichi_lib/generic.py:371-404
-          const float axv = g2v.x, ayv = g2v.y, sxv = gs_rcp_fast(g2v.z), syv = gs_rcp_fast(g2v.w);
+          // taichi_lib/generic.py:341-404 in the splat's frame: u = R(axis) d, pdf = tau fx(ux) fy(uy) with
+          // f(u; s) = s (S((u + .5) / s) - S((u - .5) / s)).  With a_k = S(z_k), d_k = S'(z_k), z_1,2 = (u +- .5) / s:
+          //   df/du = d_1 - d_2,   df/ds = (a_1 - a_2) - (z_1 d_1 - z_2 d_2)
+          // record: g0 = (mean, sx, sy), g1 = (.5 / sx, .5 / sy, alpha, mask), g2 = (axis, 1 / sx, 1 / sy)
+          const float axv = g2v.x, ayv = g2v.y;
           const float ux = dx * axv + dy * ayv, uy = dy * axv - dx * ayv;
-          float Sx1, dSx1, dSx1s, Sx2, dSx2, dSx2s, Sy1, dSy1, dSy1s, Sy2, dSy2, dSy2s;
-          s_sig_grad(ux + 0.5f, g2v.z, Sx1, dSx1, dSx1s);
-          s_sig_grad(ux - 0.5f, g2v.z, Sx2, dSx2, dSx2s);
-          s_sig_grad(uy + 0.5f, g2v.w, Sy1, dSy1, dSy1s);
-          s_sig_grad(uy - 0.5f, g2v.w, Sy2, dSy2, dSy2s);
+          const float zx1 = __builtin_fmaf(ux, g2v.z, g1v.x), zx2 = __builtin_fmaf(ux, g2v.z, -g1v.x);
+          const float zy1 = __builtin_fmaf(uy, g2v.w, g1v.y), zy2 = __builtin_fmaf(uy, g2v.w, -g1v.y);
+          float ax1, dx1, ax2, dx2, ay1, dy1, ay2, dy2;
+          s_sig_parts(zx1, ax1, dx1);
+          s_sig_parts(zx2, ax2, dx2);
+          s_sig_parts(zy1, ay1, dy1);
+          s_sig_parts(zy2, ay2, dy2);
+          const float Dx = ax1 - ax2, Dy = ay1 - ay2;
+          const float fx = g0v.z * Dx, fy = g0v.w * Dy;
           const float tau = 6.28318530717958648f;
-          const float ix = sxv * (Sx1 - Sx2), iy = syv * (Sy1 - Sy2);
-          p = tau * ix * iy;
-          const float dSx = iy * sxv * (dSx1 - dSx2), dSy = ix * syv * (dSy1 - dSy2);
-          dmx = tau * (dSx * -axv + dSy * ayv);
-          dmy = tau * (dSx * -ayv + dSy * -axv);
-          dsx = tau * iy * (Sx1 - Sx2 + (dSx1s - dSx2s) * sxv);
-          dsy = tau * ix * (Sy1 - Sy2 + (dSy1s - dSy2s) * syv);
-          dax = tau * (dSx * dx + dSy * dy);
-          day = tau * (dSx * dy + dSy * -dx);
+          const float fxt = tau * fx, fyt = tau * fy;
+          p = fx * fyt;
+          Px = (dx1 - dx2) * fyt;
+          Py = fxt * (dy1 - dy2);
+          dsx = (Dx - __builtin_fmaf(zx1, dx1, -(zx2 * dx2))) * fyt;
+          dsy = fxt * (Dy - __builtin_fmaf(zy1, dy1, -(zy2 * dy2)));
+          dax = __builtin_fmaf(Px, dx, Py * dy);
+          day = __builtin_fmaf(Px, dy, -(Py * dx));
+          // dmx, dmy: the wave totals of aag Px, aag Py are rotated out of the frame once per splat (epilogue)
         } else {
           tx = dx * g0v.z + dy * g0v.w;
           ty = dx * g1v.x + dy * g1v.y;
@@ -295,12 +320,22 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         for (int c = 0; c < FP; ++c) gf[c] += w * gpix[b][c];  // :201
         if (FULL) {
           const float aag = g1v.z * alpha_grad;  // :184
-          S[0] += aag * dmx; S[1] += aag * dmy;
+          if (a.aa) {
+            S[0] += aag * Px; S[1] += aag * Py;  // splat frame; see the epilogue
+            if (a.heur) {
+              dmx = -Px * g2v.x + Py * g2v.y;
+              dmy = -Px * g2v.y - Py * g2v.x;
+            }
+          } else {
+            S[0] += aag * dmx; S[1] += aag * dmy;
+          }
           S[2] += aag * dax; S[3] += aag * day;
           S[4] += aag * dsx; S[5] += aag * dsy;
           S[6] += p * alpha_grad;
-          S[7] += aag * aag;                                  // :194-198
-          S[8] += fabsf(aag * dmx) + fabsf(aag * dmy);
+          if (a.heur) {
+            S[7] += aag * aag;                                  // :194-198
+            S[8] += fabsf(aag * dmx) + fabsf(aag * dmy);
+          }
         } else {
           // moments in the (scaled) ellipse frame (tx, ty are O(1): no cancellation for elongated splats), carrying
           // the splat's opacity: G = alpha_p * pdf * dL/dalpha
@@ -422,6 +457,10 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         if (FULL) {
 #pragma unroll
           for (int c = 0; c < 7; ++c) row[c] = t[c];
+          if (a.aa) {  // the mean's gradient out of the splat frame: d ux / d mean = -axis, d uy / d mean = -perp(axis)
+            row[0] = -t[0] * ax + t[1] * ay;
+            row[1] = -t[0] * ay - t[1] * ax;
+          }
           if (a.heur) { row[7 + FP] = t[7]; row[8 + FP] = t[8]; }
         } else {
           // t = wave totals of (G, G tx, G ty, G tx^2, G tx ty, G ty^2), tx = d.axis/sx, ty = d.perp(axis)/sy.

@@ -481,8 +481,10 @@ def _counts_event(dev: torch.device):
 
 
 _FORKS = {}    # device index -> (side stream, events, GsFrameFork)
-# gs_frame_fwd runs the colour stage on a side stream underneath the tile mapper (GS_FORK_COLOURS=0: developer A/B)
-FORK_COLOURS = __import__("os").environ.get("GS_FORK_COLOURS", "1") != "0"
+# GS_FORK_COLOURS=1: gs_frame_fwd runs the colour stage on a side stream underneath the tile mapper (GsFrameFork).
+# Measured at C3: 1.103 vs 1.108 ms per frame -- the mapper's first kernels slow down by what the overlap hides (the
+# kernel trace shows region_count at 41 us instead of 13 beside the 52-us SH kernel) -- so it is OFF by default.
+FORK_COLOURS = __import__("os").environ.get("GS_FORK_COLOURS", "0") == "1"
 
 
 def _frame_fork(dev: torch.device):

@@ -83,10 +83,10 @@ def segmented_sort_pairs(keys: torch.Tensor, values: torch.Tensor, start_offset:
     if n == 0 or segs == 0:
         return keys_out, values_out
     scratch = torch.empty((n * 8,), dtype=torch.uint8, device=keys.device)
+    starts, ends = start_offset.contiguous(), end_offset.contiguous()  # named: a temporary's block could be handed out again
     nv.check(lib.gs_segmented_sort_pairs(n, keys.element_size(), nv.ptr(keys), nv.ptr(values), nv.ptr(keys_out),
-                                         nv.ptr(values_out), segs, nv.ptr(start_offset.contiguous()),
-                                         nv.ptr(end_offset.contiguous()), nv.ptr(scratch), n * 8, nv.stream()),
-             "gs_segmented_sort_pairs")
+                                         nv.ptr(values_out), segs, nv.ptr(starts), nv.ptr(ends), nv.ptr(scratch), n * 8,
+                                         nv.stream()), "gs_segmented_sort_pairs")
     return keys_out, values_out
 
 

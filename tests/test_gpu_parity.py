@@ -147,8 +147,10 @@ def test_sparse_exchange_kernels(F, col0, world, v):
         feats[rng.random((v, F)) < 0.2] = 1.0          # clamped channels
         ent = torch.empty((max(rows.shape[0], 1) + 3, W), dtype=torch.float32, device=DEV)  # + padding rows
         ent.view(torch.int32)[:, 0] = -1
-        nv.check(lib.gs_shard_pack_sparse(rows.shape[0], nv.ptr(dev(rows)), F, col0, nv.ptr(dev(grad)),
-                                          nv.ptr(dev(feats)), nv.ptr(ent), nv.stream()), "gs_shard_pack_sparse")
+        rows_d, grad_d, feats_d = dev(rows), dev(grad), dev(feats)  # named: the buffers must outlive the launch
+        nv.check(lib.gs_shard_pack_sparse(rows.shape[0], nv.ptr(rows_d), F, col0, nv.ptr(grad_d),
+                                          nv.ptr(feats_d), nv.ptr(ent), nv.stream()), "gs_shard_pack_sparse")
+        torch.cuda.synchronize()
         want = np.concatenate([rows.view(np.float32)[:, None], grad[rows, :7 + F]], 1)
         mask = ~((feats[rows] > 0) & (feats[rows] < 1))
         mask[:, :col0] = False
