@@ -67,13 +67,13 @@ __device__ __forceinline__ void s_sig_grad(float x, float inv_sigma, float& s, f
 }
 
 // The antialiased pdf's sigmoid S(z) = 1 / (1 + exp(-(1.6 z + 0.07 z^3))) (taichi_lib/generic.py:341-369) and its
-// derivative in 14 issue slots: a = S(z), d = dS/dz = (1.6 + 0.21 z^2) S (1 - S), with S (1 - S) = e a^2 for e =
-// exp(-(...)) (no 1 - S, the log2(e) factors folded into the polynomial).
+// derivative in 15 issue slots: a = S(z), d = dS/dz = (1.6 + 0.21 z^2) S (1 - S); the log2(e) factors are folded into
+// the polynomial.  (S (1 - S) as a (1 - a), not e a^2: far out in the tail e overflows to inf while a is an exact 0.)
 __device__ __forceinline__ void s_sig_parts(float z, float& a, float& d) {
   const float z2 = z * z;
   const float e = gs_exp2_fast(z * __builtin_fmaf(-0.07f * 1.44269504088896341f, z2, -1.6f * 1.44269504088896341f));
   a = gs_rcp_fast(1.0f + e);
-  d = __builtin_fmaf(0.21f, z2, 1.6f) * (e * a * a);
+  d = __builtin_fmaf(0.21f, z2, 1.6f) * (a * (1.0f - a));
 }
 
 #ifndef GS_BWD_WAVES
