@@ -12,14 +12,15 @@ def step():
     for _, t in gg.items(): t.grad = None
     r = gs.render_gaussians(gg, cam, cfg, use_sh=True)
     r.image.backward(G)
-for calls in (True, False):
-    fused.FRAME_CALLS = calls
-    for _ in range(20): step()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(300): step()
-    torch.cuda.synchronize()
-    print(f"host-bound ms/step ({'gs_frame_fwd / gs_frame_bwd' if calls else 'one entry point per stage'}):",
-          round((time.perf_counter() - t0) / 300 * 1e3, 4))
+for round_ in range(3):  # alternating, so that clock / box effects hit both alike
+    for calls in (True, False):
+        fused.FRAME_CALLS = calls
+        for _ in range(20): step()
+        torch.cuda.synchronize(); t0 = time.perf_counter(); c0 = time.process_time()
+        for _ in range(300): step()
+        c1 = time.process_time(); torch.cuda.synchronize()
+        print(f"round {round_}: ms/step ({'gs_frame_fwd / gs_frame_bwd' if calls else 'one entry point per stage'}):",
+              round((time.perf_counter() - t0) / 300 * 1e3, 4), " process CPU ms/step:", round((c1 - c0) / 300 * 1e3, 4))
 fused.FRAME_CALLS = True
 # forward and backward apart (each followed by a device synchronisation)
 tf = tb = 0.0
