@@ -154,6 +154,11 @@ int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree,
 /* Sharded frame (no reference counterpart): gs_sh_fwd for the rows whose splat can reach a tile row of
  * `shard` (points2d (v,7) from gs_project_fwd; a superset of what gs_map_prepare lists for that shard); the other rows
  * of `out` receive 0.5 ("not clamped").  shard == NULL evaluates the rows of the whole image's splats. */
+/* Sharded frame, the colours of a LIST of rows (the mapper's touched list, gs_map_touched_list): row ids rows[0 ..
+ * *rows_count) (both on the device; v = capacity of the list), out row = the listed row, nothing else is written. */
+int gs_sh_fwd_rows(int64_t v, const int32_t* rows, const int32_t* rows_count, int32_t channels, int32_t degree,
+                   const float* params, const float* positions, const int64_t* indexes, const float* camera_pos,
+                   float* out, int32_t out_stride, void* stream);
 int gs_sh_fwd_shard(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,
                     const float* positions, const int64_t* indexes, const float* camera_pos, const float* points2d,
                     int32_t height, const GsRasterConfig* cfg, const GsRowShard* shard, float* out,
@@ -180,10 +185,11 @@ int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_features, i
  * arrays of `world` device pointers / entry counts (padding beyond a list's count is not read).  One pass: every row of
  * colour_out / splat_out is WRITTEN (zeros where no list has it -- the buffers need not be cleared), the lists are
  * summed in rank order inside each 256-row tile, so every rank gets the same bits, as with gs_shard_add_sparse list by
- * list.  tmp: 4 * world * (ceil(v / 256) + 1) bytes. */
+ * list.  row_range (optional, device int32[2], from gs_map_touched_list's owned_rows): only the 256-row tiles that
+ * meet [first, last) are written (sharded gradients: nothing else is read).  tmp: 4 * world * (ceil(v / 256) + 1) bytes. */
 int gs_shard_merge_sparse(int32_t world, const float* const* entries_host, const int64_t* counts_host,
                           int32_t num_features, int32_t colour_col0, int64_t v, float* colour_out, float* splat_out,
-                          void* tmp, int64_t tmp_bytes, void* stream);
+                          const int32_t* row_range, void* tmp, int64_t tmp_bytes, void* stream);
 int gs_sh_bwd(int64_t n, int64_t v, int32_t channels, int32_t degree, const float* params, const float* positions,
               const int64_t* indexes, int32_t indexes_unique, const int32_t* slot_of, const float* camera_pos,
               const float* grad_out, int32_t grad_out_stride, const float* fwd_out, int32_t fwd_out_stride,
@@ -231,10 +237,11 @@ int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles);
  * forwards.  With owner_counts (world int64, optional): rank r owns the Gaussians [r chunk, (r + 1) chunk), chunk =
  * ceil(n / world), and since rows ascend with the Gaussian index (indexes (v) int64 from gs_project_fwd) the rows of one
  * owner are contiguous in the list -- owner_counts[r] = how many belong to owner r: the send counts of the all-to-all of
- * grad_mode "sharded". */
+ * grad_mode "sharded".  count_out (optional, device int32) receives M.  owned_rows (optional, device int32[2], with
+ * owner_counts): the row range [first, last) of the visible list whose Gaussians rank `owner` owns. */
 int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_tiles, const void* scratch, int64_t scratch_bytes,
-                        int32_t* touched_out, const int64_t* indexes, int64_t n, int32_t world, int64_t* owner_counts,
-                        void* stream);
+                        int32_t* touched_out, int32_t* count_out, const int64_t* indexes, int64_t n, int32_t world,
+                        int64_t* owner_counts, int32_t owner, int32_t* owned_rows, void* stream);
 int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                    const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
                    int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,
@@ -382,13 +389,19 @@ typedef struct GsFrame {
   /* render_depth: cfg.forward_cut for the rasterizer call that blends [z, z^2, features] -- the caller divides its
    * forward_cut by far^2 (GsRasterConfig.forward_cut above); the mapper and the median-depth pass use cfg as it is */
   float depth_forward_cut;
+  /* Sharded frame with a sparse exchange (has_shard; 0 = none): the number of ranks.  The forward then also leaves the
+   * ascending list of the touched rows in the workspace (layout.touched; count in counts[1]; per-owner counts in
+   * layout.owner_counts; the row range of the Gaussians rank exchange_rank owns in counts[2..3]) and evaluates SH
+   * colours for exactly those rows (gs_sh_fwd_rows; every other colour is 0.5) instead of testing every row against
+   * the rank's rows (gs_sh_fwd_shard). */
+  int32_t exchange_world, exchange_rank;
 } GsFrame;
 
 typedef struct GsFrameLayout {
   int64_t workspace_bytes, fwd_scratch_bytes, bwd_scratch_bytes, stage_bytes;
   /* workspace */
   int64_t counts, camera_pos, points, depth, features, indexes, slot_of, tile_ranges, tile_order, overlap_to_point,
-      image, alpha, visibility, out_image, img_depth, img_var, median, grad_rows;
+      image, alpha, visibility, out_image, img_depth, img_var, median, grad_rows, touched, owner_counts;
   /* forward scratch */
   int64_t s_ndc_depth, s_pairs, s_median_cover, s_stage;
   /* backward scratch */

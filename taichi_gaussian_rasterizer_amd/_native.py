@@ -40,7 +40,7 @@ class GsFrame(ctypes.Structure):
                 ("near_plane", c_double), ("far_plane", c_double), ("render_depth", c_int32), ("use_depth16", c_int32),
                 ("render_median_depth", c_int32), ("prepare_backward", c_int32), ("k_capacity", c_int64),
                 ("max_tile_hint", c_int32), ("has_shard", c_int32), ("shard", GsRowShard), ("cfg", GsRasterConfig),
-                ("depth_forward_cut", c_float)]
+                ("depth_forward_cut", c_float), ("exchange_world", c_int32), ("exchange_rank", c_int32)]
 
 
 class GsFrameFork(ctypes.Structure):
@@ -53,7 +53,7 @@ class GsFrameLayout(ctypes.Structure):
     _OFFSETS = ("workspace_bytes", "fwd_scratch_bytes", "bwd_scratch_bytes", "stage_bytes",
                 "counts", "camera_pos", "points", "depth", "features", "indexes", "slot_of", "tile_ranges", "tile_order",
                 "overlap_to_point", "image", "alpha", "visibility", "out_image", "img_depth", "img_var", "median",
-                "grad_rows", "s_ndc_depth", "s_pairs", "s_median_cover", "s_stage", "b_grad_image", "b_camera",
+                "grad_rows", "touched", "owner_counts", "s_ndc_depth", "s_pairs", "s_median_cover", "s_stage", "b_grad_image", "b_camera",
                 "b_grad_rows")
     _fields_ = [(name, c_int64) for name in _OFFSETS] + [
         ("num_features", c_int32), ("grad_row_floats", c_int32), ("tiles_x", c_int32), ("tiles_y", c_int32),
@@ -84,6 +84,7 @@ SIGNATURES = {
                                        _I32, _P, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "gs_camera_position": (ctypes.c_int, [_P, _P, _P]),
     "gs_sh_fwd": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
+    "gs_sh_fwd_rows": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _P]),
     "gs_sh_fwd_shard": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P, _P, _I32, _CFG, _SHARD, _P, _I32, _P]),
     "gs_shard_pack_grads": (ctypes.c_int, [_I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "gs_sh_bwd": (ctypes.c_int, [_I64, _I64, _I32, _I32, _P, _P, _P, _I32, _P, _P, _P, _I32, _P, _I32, _P, _P, _P,
@@ -92,8 +93,8 @@ SIGNATURES = {
     "gs_map_touched_offset": (_I64, [_I64, _I64]),
     "gs_shard_pack_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _P, _P, _P, _P]),
     "gs_shard_add_sparse": (ctypes.c_int, [_I64, _P, _I32, _I32, _I64, _P, _P, _P]),
-    "gs_shard_merge_sparse": (ctypes.c_int, [_I32, _P, _P, _I32, _I32, _I64, _P, _P, _P, _I64, _P]),
-    "gs_map_touched_list": (ctypes.c_int, [_I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _P, _P]),
+    "gs_shard_merge_sparse": (ctypes.c_int, [_I32, _P, _P, _I32, _I32, _I64, _P, _P, _P, _P, _I64, _P]),
+    "gs_map_touched_list": (ctypes.c_int, [_I64, _P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _I32, _P, _P]),
     "gs_map_prepare": (ctypes.c_int, [_I64, _P, _P, _I32, _I32, _CFG, _I64, _P, _P, _P, _P, _SHARD, _P, _I64, _P]),
     "gs_map_finish": (ctypes.c_int, [_I64, _P, _I64, _I32, _P, _P, _I32, _I32, _CFG, _I32, _P, _P, _P, _P, _SHARD,
                                       _P, _I64, _P]),

@@ -154,10 +154,12 @@ __global__ __launch_bounds__(256) void sparse_cuts_kernel(MergeLists lists, int 
 
 __global__ __launch_bounds__(256) void sparse_merge_kernel(MergeLists lists, int world, int F, int col0, int64_t v,
                                                            int num_blocks, const int* cuts, float* colour,
-                                                           float* splat) {
+                                                           float* splat, const int* row_range) {
   extern __shared__ float s_rows[];  // MERGE_ROWS x (7 + F)
   const int width = 8 + F, cols = 7 + F;
   const int64_t row0 = int64_t(blockIdx.x) * MERGE_ROWS;
+  // sharded gradients: only the rows of the Gaussians this rank owns are ever read -- tiles outside are not written
+  if (row_range && (row0 + MERGE_ROWS <= row_range[0] || row0 >= row_range[1])) return;
   for (int e = threadIdx.x; e < MERGE_ROWS * cols; e += 256) s_rows[e] = 0.0f;
   __syncthreads();
   const int sub = threadIdx.x >> 4, c = threadIdx.x & 15;  // 16 lanes per entry, 16 entries per step
@@ -229,7 +231,8 @@ extern "C" int gs_shard_add_sparse(int64_t m, const float* entries, int32_t num_
 
 extern "C" int gs_shard_merge_sparse(int32_t world, const float* const* entries_host, const int64_t* counts_host,
                                      int32_t num_features, int32_t colour_col0, int64_t v, float* colour_out,
-                                     float* splat_out, void* tmp, int64_t tmp_bytes, void* stream) {
+                                     float* splat_out, const int32_t* row_range, void* tmp, int64_t tmp_bytes,
+                                     void* stream) {
   GS_REQUIRE(num_features >= 1 && num_features <= GS_MAX_FEATURES && colour_col0 >= 0 && colour_col0 < num_features,
              GS_ERR_INVALID_ARGUMENT, "gs_shard_merge_sparse: %d features, colours from column %d", num_features,
              colour_col0);
@@ -252,7 +255,7 @@ extern "C" int gs_shard_merge_sparse(int32_t world, const float* const* entries_
   hipLaunchKernelGGL(sparse_cuts_kernel, dim3(unsigned(gs_div_up(searches, 256))), dim3(256), 0, s, lists, world,
                      8 + num_features, nb, cuts);
   hipLaunchKernelGGL(sparse_merge_kernel, dim3(nb), dim3(256), size_t(MERGE_ROWS) * (7 + num_features) * 4, s, lists,
-                     world, num_features, colour_col0, v, nb, cuts, colour_out, splat_out);
+                     world, num_features, colour_col0, v, nb, cuts, colour_out, splat_out, row_range);
   GS_CHECK_LAUNCH("gs_shard_merge_sparse");
   return GS_OK;
 }

@@ -110,6 +110,9 @@ extern "C" int gs_frame_layout(const GsFrame* f, GsFrameLayout* out) {
   out->img_var = f->render_depth ? take(d.P * 4) : -1;
   out->median = f->render_median_depth ? take(d.P * 4) : -1;
   out->grad_rows = f->prepare_backward ? take(n * d.RS * 4) : -1;
+  const bool lists = f->has_shard && f->exchange_world > 0;
+  out->touched = lists ? take(n * 4) : -1;
+  out->owner_counts = lists ? take(64 * 8) : -1;
   out->workspace_bytes = p;
   // ---- forward scratch (dead when gs_frame_fwd's work has run): projection and mapper scratch take turns
   p = 0;
@@ -172,6 +175,16 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   float* ndc = at<float>(scratch, L.s_ndc_depth);
   void* stage = at<char>(scratch, L.s_stage);
 
+  const bool lists = shard && f->exchange_world > 0 && d.T > 0;
+  GS_REQUIRE(f->exchange_world <= 64 && (f->exchange_world == 0 || (f->exchange_rank >= 0 && f->exchange_rank < f->exchange_world)),
+             GS_ERR_INVALID_ARGUMENT, "gs_frame_fwd: exchange rank %d of %d", f->exchange_rank, f->exchange_world);
+  if (lists && f->sh_degree >= 0 &&
+      hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(feats), 0x3F000000, size_t(d.n) * d.F, s) != hipSuccess) {
+    // 0.5 = "not clamped" for the colours of the rows this rank never evaluates (see gs_sh_fwd_shard); before the
+    // projection, whose compaction pass writes the depth feature columns
+    gs_set_error("gs_frame_fwd: hipMemsetD32Async failed");
+    return GS_ERR_LAUNCH;
+  }
   tm.mark(GS_FWD_PROJECT, 0, stream);
   if (int rc = gs_project_fwd_ex(d.n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
                                  f->width, f->height, f->near_plane, f->far_plane, cfg, points, depth, ndc, indexes,
@@ -198,7 +211,9 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     colour_stream = fork->side_stream;
   }
   tm.mark(GS_FWD_COLOURS, 0, colour_stream);
-  if (f->sh_degree >= 0 && shard)
+  if (f->sh_degree >= 0 && lists)
+    rc = GS_OK;  // after the mapper's first half, on its list of touched rows (below)
+  else if (f->sh_degree >= 0 && shard)
     rc = gs_sh_fwd_shard(d.n, v_dev, d.C, f->sh_degree, feature, position, indexes, cam_pos, points, f->height, cfg,
                          shard, colours, d.F, colour_stream);
   else if (f->sh_degree >= 0)
@@ -218,7 +233,11 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   }
   if (d.T == 0) {
     // this rank owns no tile row (more ranks than rows): nothing to map or rasterize, only V is needed
-    if (hipMemsetAsync(counts + 4, 0, 16, s) != hipSuccess) { gs_set_error("gs_frame_fwd: memset failed"); return GS_ERR_LAUNCH; }
+    if (hipMemsetAsync(counts + 1, 0, 28, s) != hipSuccess) { gs_set_error("gs_frame_fwd: memset failed"); return GS_ERR_LAUNCH; }
+    if (L.owner_counts >= 0 && hipMemsetAsync(at<char>(workspace, L.owner_counts), 0, 64 * 8, s) != hipSuccess) {
+      gs_set_error("gs_frame_fwd: memset failed");
+      return GS_ERR_LAUNCH;
+    }
     if (counts_host) {
       if (hipMemcpyAsync(counts_host, counts + 4, 16, hipMemcpyDeviceToHost, s) != hipSuccess ||
           hipMemcpyAsync(counts_host + 4, counts, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -243,6 +262,20 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   if (counts_event && hipEventRecord(static_cast<hipEvent_t>(counts_event), s) != hipSuccess) {
     gs_set_error("gs_frame_fwd: hipEventRecord failed");
     return GS_ERR_LAUNCH;
+  }
+  if (lists) {
+    int32_t* touched = at<int32_t>(workspace, L.touched);
+    if ((rc = gs_map_touched_list(d.n, v_dev, d.T, stage, L.stage_bytes, touched, counts + 1, indexes, d.n,
+                                  f->exchange_world, at<int64_t>(workspace, L.owner_counts), f->exchange_rank,
+                                  counts + 2, stream)))
+      return rc;
+    if (f->sh_degree >= 0) {
+      tm.mark(GS_FWD_COLOURS, 0, stream);
+      if ((rc = gs_sh_fwd_rows(d.n, touched, counts + 1, d.C, f->sh_degree, feature, position, indexes, cam_pos, colours,
+                               d.F, stream)))
+        return rc;
+      tm.mark(GS_FWD_COLOURS, 1, stream);
+    }
   }
   const int32_t tile_hint = f->max_tile_hint > 0 ? -f->max_tile_hint : 0;  // a sizing hint: fuller tiles are still sorted
   tm.mark(GS_FWD_MAP_FINISH, 0, stream);

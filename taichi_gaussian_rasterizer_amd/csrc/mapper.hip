@@ -1171,7 +1171,7 @@ namespace {
 // ascending list of the rows with region_of >= 0: a stable compaction on the per-workgroup counts the binning pass
 // left (every workgroup adds up the counts in front of it, as the projection's compaction does)
 __global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const int* v_dev, const int* region_of,
-                                                             const int* block_counts, int* touched) {
+                                                             const int* block_counts, int* touched, int* count_out) {
   __shared__ int s_wave[16];
   __shared__ int s_before[16];
   const int64_t live = v_dev ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
@@ -1189,11 +1189,17 @@ __global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const in
   for (int w = 0; w < 16; ++w) base += s_before[w];
   for (int w = 0; w < wave; ++w) base += s_wave[w];
   if (flag) touched[base + __popcll(b & ((1ull << lane) - 1ull))] = int(i);
+  if (count_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) {  // the last thread knows the total
+    int total = base + __popcll(b);
+    for (int w = wave + 1; w < 16; ++w) total += s_wave[w];  // (wave 15 here: nothing behind it)
+    *count_out = total;
+  }
 }
 
 // owner r's share of the ascending list: [first row whose Gaussian index >= r chunk, ... (r + 1) chunk)
 __global__ void owner_cuts_kernel(const int* block_counts, int num_blocks, const int* touched, const int64_t* indexes,
-                                  int64_t chunk, int world, int64_t* owner_counts) {
+                                  int64_t chunk, int world, int64_t* owner_counts, const int* v_dev, int64_t v,
+                                  int owner, int* owned_rows) {
   __shared__ int64_t s_cut[65];
   __shared__ int s_part[128];
   const int t = threadIdx.x;
@@ -1214,12 +1220,24 @@ __global__ void owner_cuts_kernel(const int* block_counts, int num_blocks, const
   }
   __syncthreads();
   if (t < world) owner_counts[t] = s_cut[t + 1] - s_cut[t];
+  // the rows (of the whole visible list, not only the touched ones) whose Gaussians `owner` owns: [first row with
+  // index >= owner chunk, first row with index >= (owner + 1) chunk)
+  if (owned_rows && t >= 126) {
+    const int64_t bound = int64_t(owner + (t - 126)) * chunk;
+    int64_t lo = 0, hi = v_dev ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (indexes[mid] < bound) lo = mid + 1; else hi = mid;
+    }
+    owned_rows[t - 126] = int(lo);
+  }
 }
 }  // namespace
 
 extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_tiles, const void* scratch,
-                                   int64_t scratch_bytes, int32_t* touched_out, const int64_t* indexes, int64_t n,
-                                   int32_t world, int64_t* owner_counts, void* stream) {
+                                   int64_t scratch_bytes, int32_t* touched_out, int32_t* count_out,
+                                   const int64_t* indexes, int64_t n, int32_t world, int64_t* owner_counts,
+                                   int32_t owner, int32_t* owned_rows, void* stream) {
   GS_REQUIRE(v >= 0 && v < (int64_t(1) << 31) && num_tiles >= 1, GS_ERR_INVALID_ARGUMENT, "gs_map_touched_list: sizes");
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (owner_counts) {
@@ -1230,6 +1248,10 @@ extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_
       return GS_ERR_LAUNCH;
     }
   }
+  if (count_out && v == 0 && hipMemsetAsync(count_out, 0, 4, s) != hipSuccess) {
+    gs_set_error("gs_map_touched_list: hipMemsetAsync failed");
+    return GS_ERR_LAUNCH;
+  }
   if (v == 0) return GS_OK;
   const int nb = int(gs_div_up(v, 1024));
   GS_REQUIRE(scratch && scratch_bytes >= gs_map_scratch_bytes(v, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
@@ -1237,10 +1259,14 @@ extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_
   GS_REQUIRE(touched_out, GS_ERR_INVALID_ARGUMENT, "gs_map_touched_list: touched_out is NULL");
   const MapScratch m = carve(const_cast<void*>(scratch), v, num_tiles);
   const int* block_counts = m.touched_blocks;  // BIN = 1024 rows per workgroup of the binning pass
-  hipLaunchKernelGGL(touched_write_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts, touched_out);
-  if (owner_counts)
+  hipLaunchKernelGGL(touched_write_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts, touched_out,
+                     count_out);
+  if (owner_counts) {
+    GS_REQUIRE(!owned_rows || (owner >= 0 && owner < world), GS_ERR_INVALID_ARGUMENT,
+               "gs_map_touched_list: owned_rows needs the owner's rank");
     hipLaunchKernelGGL(owner_cuts_kernel, dim3(1), dim3(128), 0, s, block_counts, nb, touched_out, indexes,
-                       gs_div_up(n > 0 ? n : 1, world), world, owner_counts);
+                       gs_div_up(n > 0 ? n : 1, world), world, owner_counts, v_dev, v, owner, owned_rows);
+  }
   GS_CHECK_LAUNCH("gs_map_touched_list");
   return GS_OK;
 }

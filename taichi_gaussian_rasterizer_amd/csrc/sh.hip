@@ -83,6 +83,8 @@ __device__ __forceinline__ void load_row(const float* row, float* out) {
 #define GS_SH_ROW_MARGIN 2
 #endif
 struct ShTouch {
+  const int* rows;        // optional: evaluate exactly these rows (a list of *rows_count row ids), nothing else is written
+  const int* rows_count;
   const float* points2d;  // (v, 7) projected splats, NULL = evaluate every row
   GsShard sh;
   float inv_tile, thr;
@@ -106,7 +108,11 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev
                                                      const float* positions, const int64_t* indexes,
                                                      const float* cam, float* out, int out_stride, const ShTouch touch) {
   constexpr int D = (DEG + 1) * (DEG + 1);
-  const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+  if (touch.rows != nullptr) {  // row list (sharded frame: the mapper's list of the splats that can reach the rank's rows)
+    if (i >= v || i >= *touch.rows_count) return;
+    i = touch.rows[i];
+  }
   if (v_dev != nullptr && i >= *v_dev) return;
   if (i >= v) return;
   if (touch.points2d != nullptr && !sh_touched(touch, i)) {
@@ -371,6 +377,17 @@ extern "C" int gs_sh_fwd(int64_t v, const int32_t* v_dev, int32_t channels, int3
   touch.points2d = nullptr;
   return sh_fwd_launch(v, v_dev, channels, degree, params, positions, indexes, camera_pos, out, out_stride, touch,
                        stream, "gs_sh_fwd");
+}
+
+extern "C" int gs_sh_fwd_rows(int64_t v, const int32_t* rows, const int32_t* rows_count, int32_t channels,
+                              int32_t degree, const float* params, const float* positions, const int64_t* indexes,
+                              const float* camera_pos, float* out, int32_t out_stride, void* stream) {
+  GS_REQUIRE(rows && rows_count, GS_ERR_INVALID_ARGUMENT, "gs_sh_fwd_rows: NULL row list");
+  ShTouch touch{};
+  touch.rows = rows;
+  touch.rows_count = rows_count;
+  return sh_fwd_launch(v, nullptr, channels, degree, params, positions, indexes, camera_pos, out, out_stride, touch,
+                       stream, "gs_sh_fwd_rows");
 }
 
 extern "C" int gs_sh_fwd_shard(int64_t v, const int32_t* v_dev, int32_t channels, int32_t degree, const float* params,

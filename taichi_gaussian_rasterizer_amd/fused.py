@@ -222,7 +222,21 @@ class _FusedRender(torch.autograd.Function):
         return _backward_stages(ctx, ctx.saved_tensors, g_image, g_points, g_depth, g_img_depth, g_img_var) + (None,) * 12
 
 
-def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, scratch_offset):
+def _exchange_ranks(shard, exchange, group, n, owned_range):
+    """(world, rank) of a sharded frame's sparse exchange, (0, 0) when there is none"""
+    if shard is None or exchange != "sparse":
+        return 0, 0
+    import torch.distributed as dist
+
+    from . import parallel
+    if dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    world = max(parallel.EMULATED_WORLD, 1)
+    rank = 0 if owned_range is None else owned_range[0] // max(-(-n // world), 1)
+    return world, rank
+
+
+def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, scratch_offset, prepared=None):
     """Bookkeeping of a sharded frame's sparse exchange, done during the FORWARD: keep the mapper's list of the splats
     that can reach this rank's rows (M int32 rows, left in the mapper scratch) and start the all-gather of the list
     lengths (grad_mode "sharded": of the per-owner counts, the list sorted by Gaussian index so that the entries of one
@@ -231,26 +245,36 @@ def _start_sparse_exchange(meta, n, num_tiles, touched_count, indexes, scratch, 
 
     from . import parallel
     group = meta["group"]
-    dev = indexes.device
     world = dist.get_world_size(group) if dist.is_initialized() else max(parallel.EMULATED_WORLD, 1)
     M = int(touched_count)
     lib = nv.lib()
     sharded = meta["grad_mode"] == "sharded"
-    # the mapper's list is grouped by screen region; ascending rows (= ascending Gaussian index) make the exchange
-    # kernels walk memory forwards and put the rows of one owner rank next to each other
-    touched = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
-    counts = torch.empty((world if sharded else 1,), dtype=torch.int64, device=dev)
-    mbytes = lib.gs_map_scratch_bytes(n, max(num_tiles, 1))
-    if num_tiles > 0 and M > 0:
-        nv.check(lib.gs_map_touched_list(n, nv.ptr(meta["v_dev"]), max(num_tiles, 1),
-                                         ctypes.c_void_p(scratch.data_ptr() + scratch_offset), mbytes, nv.ptr(touched),
-                                         nv.ptr(indexes), n, world, nv.ptr(counts) if sharded else None, nv.stream()),
-                 "gs_map_touched_list")
-    elif sharded:
-        counts.zero_()
-    if not sharded:
-        counts.fill_(M)
-    touched = touched[:M]
+    rank = dist.get_rank(group) if dist.is_initialized() else \
+        (0 if meta.get("owned_range") is None else meta["owned_range"][0] // max(-(-n // world), 1))
+    if prepared is not None:  # gs_frame_fwd did it (and evaluated the colours of exactly these rows)
+        touched = prepared["touched"]
+        counts = prepared["owner_counts"] if sharded else torch.full((1,), M, dtype=torch.int64, device=touched.device)
+        meta["owned_rows"] = prepared["owned_rows"] if sharded else None
+    else:
+        dev = indexes.device
+        # the mapper's list is grouped by screen region; ascending rows (= ascending Gaussian index) make the exchange
+        # kernels walk memory forwards and put the rows of one owner rank next to each other
+        touched = torch.empty((max(n, 1),), dtype=torch.int32, device=dev)
+        counts = torch.empty((world if sharded else 1,), dtype=torch.int64, device=dev)
+        owned_rows = torch.zeros((2,), dtype=torch.int32, device=dev) if sharded else None
+        mbytes = lib.gs_map_scratch_bytes(n, max(num_tiles, 1))
+        if num_tiles > 0 and M > 0:
+            nv.check(lib.gs_map_touched_list(n, nv.ptr(meta["v_dev"]), max(num_tiles, 1),
+                                             ctypes.c_void_p(scratch.data_ptr() + scratch_offset), mbytes,
+                                             nv.ptr(touched), None, nv.ptr(indexes), n, world,
+                                             nv.ptr(counts) if sharded else None, rank, nv.ptr(owned_rows),
+                                             nv.stream()), "gs_map_touched_list")
+        elif sharded:
+            counts.zero_()
+        if not sharded:
+            counts.fill_(M)
+        touched = touched[:M]
+        meta["owned_rows"] = owned_rows if (sharded and num_tiles > 0 and M > 0) else None
     meta["touched"] = touched
     meta["touched_count"] = M
     meta["sizes"] = parallel.SizesFuture(counts, group) if world > 1 else None
@@ -349,8 +373,9 @@ def _backward_stages(ctx, saved, g_image, g_points, g_depth, g_img_depth, g_img_
             cnts = (ctypes.c_int64 * nl)(*[cnt for _, cnt in lists])
             tmp_bytes = 4 * nl * (-(-rows_n // 256) + 1)
             tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=dev)
-            nv.check(lib.gs_shard_merge_sparse(nl, ptrs, cnts, F, col0, rows_n, nv.ptr(pf), nv.ptr(pp), nv.ptr(tmp),
-                                               tmp_bytes, s), "gs_shard_merge_sparse")
+            nv.check(lib.gs_shard_merge_sparse(nl, ptrs, cnts, F, col0, rows_n, nv.ptr(pf), nv.ptr(pp),
+                                               nv.ptr(m.get("owned_rows")), nv.ptr(tmp), tmp_bytes, s),
+                     "gs_shard_merge_sparse")
             g_feat, g_feat_stride = nv.ptr(pf), C
             g_pts, g_pts_stride = pp, 7 + col0
         elif m["shard"] is not None:
@@ -441,10 +466,10 @@ class _Overflow(Exception):
 
 
 def _frame_for(n, C, degree, w, full_h, depth_range, render_depth, use_depth16, render_median, prepare_backward,
-               k_cap, tile_hint, shard, config):
+               k_cap, tile_hint, shard, config, exchange_world=0, exchange_rank=0):
     key = (n, C, degree, w, full_h, float(depth_range[0]), float(depth_range[1]), render_depth, use_depth16,
            render_median, prepare_backward, k_cap, tile_hint, shard, config, nv.TUNING["wave_sub_blocks"],
-           nv.TUNING["no_heavy_split"])
+           nv.TUNING["no_heavy_split"], exchange_world, exchange_rank)
     hit = _FRAMES.get(key)
     if hit is None:
         frame = nv.GsFrame()
@@ -459,6 +484,7 @@ def _frame_for(n, C, degree, w, full_h, depth_range, render_depth, use_depth16, 
                                         int(shard.phase))
         frame.cfg = nv.make_config(config)
         frame.depth_forward_cut = nv.make_config(config, cut_scale=float(depth_range[1]) ** 2).forward_cut
+        frame.exchange_world, frame.exchange_rank = int(exchange_world), int(exchange_rank)
         layout = nv.GsFrameLayout()
         nv.check(nv.lib().gs_frame_layout(ctypes.byref(frame), ctypes.byref(layout)), "gs_frame_layout")
         if len(_FRAMES) > 256:
@@ -527,8 +553,9 @@ class _FrameRender(torch.autograd.Function):
         needs_grad = any(ctx.needs_input_grad[:7])
         # a sharded frame's backward runs stage by stage (the exchange sits in its middle) and clears its own rows
         prepare_backward = needs_grad and shard is None
+        ex_world, ex_rank = _exchange_ranks(shard, exchange, group, n, owned_range)
         frame, L = _frame_for(n, C, degree, w, full_h, depth_range, render_depth, use_depth16, render_median,
-                              prepare_backward, k_cap, tile_hint, shard, config)
+                              prepare_backward, k_cap, tile_hint, shard, config, ex_world, ex_rank)
         T = T_camera_world.contiguous()
         proj = projection.contiguous()
         ws = torch.empty((L.workspace_bytes,), dtype=torch.uint8, device=dev)
@@ -581,9 +608,13 @@ class _FrameRender(torch.autograd.Function):
                         exchange=exchange, grad_mode=grad_mode, owned_range=owned_range)
         if shard is not None and exchange == "sparse":
             T_tiles = L.tiles_x * L.tiles_y
-            ctx.meta["v_dev"] = ws.view(torch.int32).as_strided((8,), (1,), L.counts // 4)
-            _start_sparse_exchange(ctx.meta, n, T_tiles, host[5] if T_tiles > 0 else 0,
-                                   ws.view(torch.int64).as_strided((n,), (1,), L.indexes // 8), scratch, L.s_stage)
+            # the frame call has already compacted the list (ascending rows) and cut it by owner: views of the workspace
+            i32 = ws.view(torch.int32)
+            M = int(host[5]) if T_tiles > 0 else 0
+            prepared = dict(touched=i32.as_strided((M,), (1,), L.touched // 4),
+                            owner_counts=ws.view(torch.int64).as_strided((ex_world,), (1,), L.owner_counts // 8),
+                            owned_rows=i32.as_strided((2,), (1,), L.counts // 4 + 2))
+            _start_sparse_exchange(ctx.meta, n, T_tiles, M, None, None, 0, prepared=prepared)
         if holder is not None and shard is not None:
             holder["touched_count"] = int(host[5]) if L.tiles_x * L.tiles_y > 0 else 0
         ctx.camera_grads = (ctx.needs_input_grad[5], ctx.needs_input_grad[6])

@@ -109,7 +109,7 @@ def test_frame_layout_is_computed_on_the_host():
     layouts seen through ctypes are the header's; bad frames are refused before anything is launched"""
     lib = _native.lib()
     cfg = _native.GsRasterConfig(tile_size=16, alpha_threshold=1 / 255., forward_cut=2.0 ** -20)
-    assert ctypes.sizeof(_native.GsFrame) == 160 and ctypes.sizeof(_native.GsFrameLayout) == 29 * 8 + 5 * 4 + 4
+    assert ctypes.sizeof(_native.GsFrame) == 168 and ctypes.sizeof(_native.GsFrameLayout) == 31 * 8 + 5 * 4 + 4
 
     def frame(**kw):
         f = _native.GsFrame(n=1000, channels=3, sh_degree=3, width=100, height=70, near_plane=0.1, far_plane=100.0,
@@ -127,7 +127,8 @@ def test_frame_layout_is_computed_on_the_host():
     assert offs == sorted(offs) and offs[0] == 0 and all(o % 256 == 0 for o in offs)
     assert lay.alpha + 100 * 70 * 4 <= lay.workspace_bytes
     assert lay.points - lay.camera_pos >= 12 and lay.depth - lay.points >= 1000 * 28
-    for k in ("visibility", "out_image", "img_depth", "img_var", "median", "grad_rows", "s_median_cover", "b_grad_image"):
+    for k in ("visibility", "out_image", "img_depth", "img_var", "median", "grad_rows", "touched", "owner_counts",
+              "s_median_cover", "b_grad_image"):
         assert getattr(lay, k) == -1, k
     assert lay.b_grad_rows >= 0 and lay.bwd_scratch_bytes >= 1000 * 64
     assert lay.stage_bytes >= max(lib.gs_project_scratch_bytes(1000), lib.gs_map_scratch_bytes(1000, 35))
@@ -145,6 +146,10 @@ def test_frame_layout_is_computed_on_the_host():
     assert (lay.tiles_y, lay.local_height) == (2, 32)
     sh = frame(has_shard=1, shard=_native.GsRowShard(3, 5, 5, 1, 0))
     assert lib.gs_frame_layout(ctypes.byref(sh), ctypes.byref(lay)) == 0 and lay.local_height == 70 - 48
+    assert lay.touched == -1
+    sh = frame(has_shard=1, shard=_native.GsRowShard(3, 5, 5, 1, 0), exchange_world=8, exchange_rank=3)
+    assert lib.gs_frame_layout(ctypes.byref(sh), ctypes.byref(lay)) == 0
+    assert lay.touched > 0 and lay.owner_counts >= lay.touched + 1000 * 4 and lay.owner_counts + 512 <= lay.workspace_bytes
 
     assert lib.gs_frame_layout(ctypes.byref(frame(k_capacity=0)), ctypes.byref(lay)) == -1
     assert lib.gs_frame_layout(ctypes.byref(frame(sh_degree=4)), ctypes.byref(lay)) == -2

@@ -179,9 +179,18 @@ def test_sparse_exchange_kernels(F, col0, world, v):
     cnts = (ctypes.c_int64 * world)(*counts)
     tmp_bytes = 4 * world * (-(-v // 256) + 1)
     tmp = torch.empty((tmp_bytes,), dtype=torch.uint8, device=DEV)
-    nv.check(lib.gs_shard_merge_sparse(world, ptrs, cnts, F, col0, v, nv.ptr(mf), nv.ptr(mp_), nv.ptr(tmp), tmp_bytes,
-                                       nv.stream()), "gs_shard_merge_sparse")
+    nv.check(lib.gs_shard_merge_sparse(world, ptrs, cnts, F, col0, v, nv.ptr(mf), nv.ptr(mp_), None, nv.ptr(tmp),
+                                       tmp_bytes, nv.stream()), "gs_shard_merge_sparse")
     assert torch.equal(mp_, pp) and torch.equal(mf, pf)
+    # with a row range only the tiles that meet it are written (sharded gradients read nothing else)
+    lo, hi = v // 3, v // 3 + max(v // 4, 1)
+    rng_d = torch.tensor([lo, hi], dtype=torch.int32, device=DEV)
+    mf.fill_(float("nan")); mp_.fill_(float("nan"))
+    nv.check(lib.gs_shard_merge_sparse(world, ptrs, cnts, F, col0, v, nv.ptr(mf), nv.ptr(mp_), nv.ptr(rng_d),
+                                       nv.ptr(tmp), tmp_bytes, nv.stream()), "gs_shard_merge_sparse")
+    assert torch.equal(mp_[lo:hi], pp[lo:hi]) and torch.equal(mf[lo:hi], pf[lo:hi])
+    t0, t1 = (lo // 256) * 256, min(-(-hi // 256) * 256, v)
+    assert bool(torch.isnan(mp_[:t0]).all()) and bool(torch.isnan(mp_[t1:]).all())
 
 
 def test_hip_lib_cumsum_and_sort():
