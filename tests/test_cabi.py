@@ -162,3 +162,25 @@ def test_frame_layout_is_computed_on_the_host():
     assert rc == -4 and b"workspace" in lib.gs_last_error()
     rc = lib.gs_frame_bwd(ctypes.byref(sh), *([None] * 7), None, 0, None, 0, 0, 0, *([None] * 13), None, None)
     assert rc == -2 and b"sharded" in lib.gs_last_error()
+
+
+def test_sparse_exchange_entry_points_validate_on_the_host():
+    """the sparse exchange's entry points (round 3) refuse bad arguments before any launch; empty calls are no-ops"""
+    lib = _native.lib()
+    assert lib.gs_shard_pack_sparse(10, None, 3, 3, None, None, None, None) == -1          # colours start inside the row
+    assert lib.gs_shard_pack_sparse(10, None, 3, 0, None, None, None, None) == -1 and b"NULL" in lib.gs_last_error()
+    assert lib.gs_shard_pack_sparse(0, None, 3, 0, None, None, None, None) == 0
+    assert lib.gs_shard_add_sparse(10, None, 40, 0, 100, None, None, None) == -1
+    assert lib.gs_shard_add_sparse(0, None, 3, 0, 100, None, None, None) == 0
+    ptrs, cnts = (ctypes.c_void_p * 2)(), (ctypes.c_int64 * 2)(0, 0)
+    assert lib.gs_shard_merge_sparse(65, ptrs, cnts, 3, 0, 100, None, None, None, None, 0, None) == -1
+    assert b"lists" in lib.gs_last_error()
+    assert lib.gs_shard_merge_sparse(2, ptrs, cnts, 3, 0, 100, ctypes.c_void_p(16), ctypes.c_void_p(16), None, None, 0,
+                                     None) == -4 and b"tmp" in lib.gs_last_error()
+    assert lib.gs_shard_merge_sparse(2, ptrs, cnts, 3, 0, 0, None, None, None, None, 0, None) == 0
+    assert lib.gs_map_touched_list(10, None, 4, None, 0, None, None, None, 10, 2, None, 0, None, None) == -4
+    assert lib.gs_map_touched_list(10, None, 4, None, 0, None, None, None, 10, 65, ctypes.c_void_p(16), 0, None,
+                                   None) == -1 and b"owners" in lib.gs_last_error()
+    assert lib.gs_map_touched_offset(1000, 64) > 0 and lib.gs_map_touched_offset(1000, 64) % 256 == 0
+    assert lib.gs_sh_fwd_rows(10, None, None, 3, 3, None, None, None, None, None, 3, None) == -1
+    assert b"row list" in lib.gs_last_error()

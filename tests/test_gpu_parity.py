@@ -193,6 +193,32 @@ def test_sparse_exchange_kernels(F, col0, world, v):
     assert bool(torch.isnan(mp_[:t0]).all()) and bool(torch.isnan(mp_[t1:]).all())
 
 
+def test_sh_forward_over_a_row_list():
+    """gs_sh_fwd_rows (the sharded frame's colour stage: exactly the rows of the mapper's touched list) writes the same
+    bits as gs_sh_fwd for the listed rows and leaves every other row alone"""
+    from taichi_gaussian_rasterizer_amd import _native as nv
+    lib = nv.lib()
+    n, v, C, deg = 5000, 4200, 3, 3
+    gen = torch.Generator().manual_seed(3)
+    params = dev(torch.randn(n, C, 16, generator=gen) * 0.3)
+    pos = dev(torch.randn(n, 3, generator=gen) * 4)
+    indexes = dev(torch.sort(torch.randperm(n, generator=gen)[:v])[0])
+    cam = dev(torch.tensor([0.1, -0.2, 0.3]))
+    full = torch.empty((v, C), device=DEV)
+    nv.check(lib.gs_sh_fwd(v, None, C, deg, nv.ptr(params), nv.ptr(pos), nv.ptr(indexes), nv.ptr(cam), nv.ptr(full), C,
+                           nv.stream()), "gs_sh_fwd")
+    rows = dev(torch.sort(torch.randperm(v, generator=gen)[:1500])[0].to(torch.int32))
+    count = dev(torch.tensor([1200], dtype=torch.int32))       # the list is longer than its live count
+    out = torch.full((v, C), -7.0, device=DEV)
+    nv.check(lib.gs_sh_fwd_rows(rows.shape[0], nv.ptr(rows), nv.ptr(count), C, deg, nv.ptr(params), nv.ptr(pos),
+                                nv.ptr(indexes), nv.ptr(cam), nv.ptr(out), C, nv.stream()), "gs_sh_fwd_rows")
+    listed = rows[:1200].long()
+    assert torch.equal(out[listed], full[listed])
+    mask = torch.ones(v, dtype=torch.bool, device=DEV)
+    mask[listed] = False
+    assert bool((out[mask] == -7.0).all())
+
+
 def test_hip_lib_cumsum_and_sort():
     rng = np.random.default_rng(0)
     for n in (1, 2, 1023, 1024, 1025, 100000, 1 << 20):
