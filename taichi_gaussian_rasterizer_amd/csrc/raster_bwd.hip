@@ -110,6 +110,7 @@ struct BwdShape {
 #endif
 constexpr int TR_STRIDE = GS_BWD_LDS_REDUCE == 1 ? 68 : 64;  // floats per value row of the transposition buffer
 constexpr int TR_ROWS = GS_BWD_LDS_REDUCE == 1 ? 8 : 4;
+// 3: hybrid -- values 0..3 in ONE 4-row LDS pass, values 4..8 through the 5-value butterfly
 
 template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int x0, int y0, int yout0, float* smem,
@@ -363,7 +364,28 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       if (any_grad) {
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
         // up owning value k stores it (one ds_write_b32 for all values of a chunk)
-        if (GS_BWD_LDS_REDUCE == 2 && NACC == 9) {
+        if (GS_BWD_LDS_REDUCE == 3 && NACC == 9) {
+          float vals[9];
+#pragma unroll
+          for (int c = 0; c < 9; ++c) vals[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) s_tr[c * TR_STRIDE + lane] = vals[c];
+          float w5[5];
+#pragma unroll
+          for (int c = 0; c < 5; ++c) w5[c] = vals[4 + c];
+          const float tot5 = gs_wave_reduce_transposed<5>(w5, lane);
+          const int slot5 = (lane & 3) == 0 ? gs_reduce_slot<5>(lane) : -1;
+          __syncthreads();
+          const float4 u = *reinterpret_cast<const float4*>(s_tr + (lane >> 4) * TR_STRIDE + (lane & 15) * 4);
+          float t = (u.x + u.y) + (u.z + u.w);
+          t = gs_dpp_add_full<0xB1>(t);
+          t = gs_dpp_add_full<0x4E>(t);
+          t = gs_dpp_add_full<0x141>(t);
+          t = gs_dpp_add_full<0x128>(t);
+          if ((lane & 15) == 0) s_acc[j][lane >> 4] = t;
+          if (slot5 >= 0) s_acc[j][4 + slot5] = tot5;
+          __syncthreads();
+        } else if (GS_BWD_LDS_REDUCE == 2 && NACC == 9) {
           // experiment (see GS_BWD_LDS_REDUCE above): in two passes of four values every lane stores its partial sums
           // as rows (value, lane), lane (c = lane >> 4, s = lane & 15) adds columns 4 s .. 4 s + 3 of row c -- one
           // conflict-free ds_read_b128 -- and four DPP adds fold the sixteen lanes of a value.  2 x (3 adds + 4 DPP) +

@@ -110,11 +110,12 @@ __global__ __launch_bounds__(256) void sh_fwd_kernel(int64_t v, const int* v_dev
   constexpr int D = (DEG + 1) * (DEG + 1);
   int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (touch.rows != nullptr) {  // row list (sharded frame: the mapper's list of the splats that can reach the rank's rows)
-    if (i >= v || i >= *touch.rows_count) return;
+    if (i >= v || i >= *touch.rows_count) return;  // v = capacity of the list here
     i = touch.rows[i];
+  } else {
+    if (v_dev != nullptr && i >= *v_dev) return;
+    if (i >= v) return;
   }
-  if (v_dev != nullptr && i >= *v_dev) return;
-  if (i >= v) return;
   if (touch.points2d != nullptr && !sh_touched(touch, i)) {
     // never rasterized here; 0.5 = "not clamped" for gs_sh_bwd's mask (the owner ranks apply the real one before the
     // gradients are summed: gs_shard_pack_grads)
