@@ -80,7 +80,8 @@ int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling
                       int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
                       float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
                       float* depth_features, int32_t depth_features_stride, float* camera_pos, void* scratch,
-                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, void* stream);
+                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, const GsMapBinPlan* bin,
+                      void* stream);
 
 extern "C" int gs_frame_layout(const GsFrame* f, GsFrameLayout* out) {
   Dims d;
@@ -114,14 +115,15 @@ extern "C" int gs_frame_layout(const GsFrame* f, GsFrameLayout* out) {
   out->touched = lists ? take(n * 4) : -1;
   out->owner_counts = lists ? take(64 * 8) : -1;
   out->workspace_bytes = p;
-  // ---- forward scratch (dead when gs_frame_fwd's work has run): projection and mapper scratch take turns
+  // ---- forward scratch (dead when gs_frame_fwd's work has run).  s_stage = [mapper scratch | projection scratch]: the
+  // projection's compaction pass reads its staged rows while it fills the mapper's region arrays (GsMapBinPlan)
   p = 0;
   out->s_ndc_depth = take(n * 4);
   out->s_pairs = take(f->k_capacity * 8);
   out->s_median_cover = f->render_median_depth ? take(d.P * 4) : -1;
   const int64_t pb = gs_project_scratch_bytes(d.n), mb = gs_map_scratch_bytes(d.n, d.T > 0 ? d.T : 1);
-  out->s_stage = take(pb > mb ? pb : mb);
-  out->stage_bytes = pb > mb ? pb : mb;
+  out->s_stage = take(a256(mb) + pb);
+  out->stage_bytes = a256(mb) + pb;
   out->fwd_scratch_bytes = p;
   // ---- backward scratch
   p = 0;
@@ -173,7 +175,10 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   float* alpha = at<float>(workspace, L.alpha);
   float* vis = L.visibility >= 0 ? at<float>(workspace, L.visibility) : nullptr;
   float* ndc = at<float>(scratch, L.s_ndc_depth);
-  void* stage = at<char>(scratch, L.s_stage);
+  void* stage = at<char>(scratch, L.s_stage);  // the mapper's part: the first map_bytes of it
+  const int64_t map_bytes = gs_map_scratch_bytes(d.n, d.T > 0 ? d.T : 1);
+  void* proj_stage = at<char>(stage, a256(map_bytes));
+  const int64_t proj_bytes = L.stage_bytes - a256(map_bytes);
 
   const bool lists = shard && f->exchange_world > 0 && d.T > 0;
   GS_REQUIRE(f->exchange_world <= 64 && (f->exchange_world == 0 || (f->exchange_rank >= 0 && f->exchange_rank < f->exchange_world)),
@@ -185,12 +190,16 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     gs_set_error("gs_frame_fwd: hipMemsetD32Async failed");
     return GS_ERR_LAUNCH;
   }
+  // the projection's compaction pass bins the visible rows by screen region for the mapper (one launch less)
+  GsMapBinPlan bin;
+  bin.width = f->width; bin.height = f->height; bin.cfg = cfg; bin.shard = shard; bin.scratch = stage;
+  bin.scratch_bytes = map_bytes;
   tm.mark(GS_FWD_PROJECT, 0, stream);
   if (int rc = gs_project_fwd_ex(d.n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection,
                                  f->width, f->height, f->near_plane, f->far_plane, cfg, points, depth, ndc, indexes,
-                                 slot_of, counts, f->render_depth ? feats : nullptr, d.F, cam_pos, stage,
-                                 L.stage_bytes, L.grad_rows >= 0 ? at<float>(workspace, L.grad_rows) : nullptr, d.RS,
-                                 stream))
+                                 slot_of, counts, f->render_depth ? feats : nullptr, d.F, cam_pos, proj_stage,
+                                 proj_bytes, L.grad_rows >= 0 ? at<float>(workspace, L.grad_rows) : nullptr, d.RS,
+                                 d.T > 0 ? &bin : nullptr, stream))
     return rc;
   tm.mark(GS_FWD_PROJECT, 1, stream);
   const int32_t* v_dev = counts;
@@ -253,8 +262,8 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
     return GS_OK;
   }
   tm.mark(GS_FWD_MAP_PREPARE, 0, stream);
-  if ((rc = gs_map_prepare(d.n, v_dev, points, f->width, f->height, cfg, f->k_capacity, tile_ranges, counts + 4,
-                           counts_host, tile_order, shard, stage, L.stage_bytes, stream)))
+  if ((rc = gs_map_prepare_ex(d.n, v_dev, points, f->width, f->height, cfg, f->k_capacity, tile_ranges, counts + 4,
+                              counts_host, tile_order, shard, stage, map_bytes, 1, stream)))
     return rc;
   tm.mark(GS_FWD_MAP_PREPARE, 1, stream);
   // K, the overflow flag and V are final here and the scan kernel has stored them into the pinned host words itself:
@@ -265,7 +274,7 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   }
   if (lists) {
     int32_t* touched = at<int32_t>(workspace, L.touched);
-    if ((rc = gs_map_touched_list(d.n, v_dev, d.T, stage, L.stage_bytes, touched, counts + 1, indexes, d.n,
+    if ((rc = gs_map_touched_list(d.n, v_dev, d.T, stage, map_bytes, touched, counts + 1, indexes, d.n,
                                   f->exchange_world, at<int64_t>(workspace, L.owner_counts), f->exchange_rank,
                                   counts + 2, stream)))
       return rc;
@@ -280,7 +289,7 @@ extern "C" int gs_frame_fwd(const GsFrame* f, const float* position, const float
   const int32_t tile_hint = f->max_tile_hint > 0 ? -f->max_tile_hint : 0;  // a sizing hint: fuller tiles are still sorted
   tm.mark(GS_FWD_MAP_FINISH, 0, stream);
   if ((rc = gs_map_finish(d.n, v_dev, f->k_capacity, tile_hint, points, ndc, f->width, f->height, cfg, f->use_depth16,
-                          tile_ranges, o2p, nullptr, at<char>(scratch, L.s_pairs), shard, stage, L.stage_bytes,
+                          tile_ranges, o2p, nullptr, at<char>(scratch, L.s_pairs), shard, stage, map_bytes,
                           stream)))
     return rc;
   tm.mark(GS_FWD_MAP_FINISH, 1, stream);

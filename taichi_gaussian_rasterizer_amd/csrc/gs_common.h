@@ -114,7 +114,37 @@ int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling
                       int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
                       float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
                       float* depth_features, int32_t depth_features_stride, float* camera_pos, void* scratch,
-                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, void* stream);
+                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, const struct GsMapBinPlan* bin,
+                      void* stream);
+// The frame calls fold the mapper's first pass (which screen region does a visible Gaussian's centre fall in, how many of
+// each region does a workgroup hold) into the projection's compaction pass, which has every visible row in registers:
+// one launch and one 28-byte read of the V rows less.  The kernel lives in mapper.hip, because what it
+// decides -- is the candidate tile span empty? -- must be the counting pass's own arithmetic, compiled with the same
+// flags (-ffp-contract=off).  gs_project_fwd_ex hands it the compaction's operands; gs_map_prepare_ex(binned = 1) then
+// starts at the region scans.
+struct GsMapBinPlan {
+  int32_t width, height;
+  const GsRasterConfig* cfg;
+  const GsRowShard* shard;  // NULL = whole image
+  void* scratch;            // the mapper scratch gs_map_prepare_ex will be given (gs_map_scratch_bytes(n, num_tiles))
+  int64_t scratch_bytes;
+};
+struct GsCompactArgs {
+  int64_t n;
+  const void* st_rows;         // (n, 2) float4 staged by the projection pass; .w of the second = depth, 0 = culled
+  const int* block_offsets;    // exclusive prefix of block_counts, or NULL (every workgroup sums the counts in front of it)
+  const int* block_counts;     // visible rows per 256 consecutive Gaussians
+  int num_blocks;              // ceil(n / 256)
+  float inv_far, ndc_denom;
+  float* points; float* depth; float* ndc; int64_t* indexes; int* slot_of; int* num_visible;
+  float* depth_feat; int depth_feat_stride;
+  void* zero_rows; int zero_row_v4;  // float4 units per row
+};
+int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* stream);
+int gs_map_prepare_ex(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
+                      const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
+                      int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,
+                      int64_t scratch_bytes, int binned, void* stream);
 // rows[i, 0..7) += add_points[i, 0..7) and rows[i, depth_col] += add_depth[i] for i < v (either may be NULL)
 int gs_rows_add(int64_t v, int32_t row_floats, float* rows, const float* add_points, const float* add_depth,
                 int32_t depth_col, void* stream);

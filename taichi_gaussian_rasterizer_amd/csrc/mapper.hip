@@ -351,14 +351,21 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
 // BIN Gaussians per workgroup: the part matrix has num_regions * ceil(V / BIN) entries, so a large BIN keeps
 // it (and its scan) small next to the V-entry arrays.
 constexpr int BIN = 1024;
+// The rows of workgroup b are [block_start[b], block_start[b + 1]): b * BIN .. here; the ranges the projection's
+// compaction pass produced when that pass did the binning itself (compact_bin_kernel below).
 __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
-                                                           int* part, int* touched_blocks) {
+                                                           int* part, int* touched_blocks, int* block_start) {
   __shared__ int s_hist[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
   __syncthreads();
   const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
   bool mine = false;
-  if (i < live_count(a)) {
+  const int64_t live = live_count(a);
+  if (threadIdx.x == 0) {
+    block_start[blockIdx.x] = int(min(int64_t(blockIdx.x) * BIN, live));
+    if (int(blockIdx.x) == num_wg - 1) block_start[num_wg] = int(live);
+  }
+  if (i < live) {
     // Gaussians whose candidate span is empty (off-screen within the cull margin; above or below this rank's
     // strip when the frame is sharded) are left out of the ordering, so the counting and bucketing passes never
     // see them.  (A non-empty span whose tiles all fail the OBB test is rare and simply contributes nothing.)
@@ -417,18 +424,106 @@ __global__ __launch_bounds__(1024) void region_scan_kernel(int num_regions, cons
 
 // K3: write the Gaussian indices grouped by region: position = region start + this workgroup's
 // offset inside the region (K2a) + rank inside the workgroup (LDS atomic).
-__global__ __launch_bounds__(BIN) void region_scatter_kernel(MapArgs a, RegionGrid rg, int num_wg, const int* region_of,
-                                                             const int* part, const int* region_start, int* order) {
+__global__ __launch_bounds__(BIN) void region_scatter_kernel(RegionGrid rg, int num_wg, const int* region_of,
+                                                             const int* part, const int* region_start,
+                                                             const int* block_start, int* order) {
   __shared__ int s_cnt[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_cnt[r] = 0;
   __syncthreads();
-  const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
-  if (i < live_count(a)) {
+  const int first = block_start[blockIdx.x];
+  const int i = first + int(threadIdx.x);
+  if (i < block_start[blockIdx.x + 1]) {
     const int r = region_of[i];
     if (r >= 0) {
       const int local = atomicAdd(&s_cnt[r], 1);
-      order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = int(i);
+      order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = i;
     }
+  }
+}
+
+// The projection's stable compaction (project.hip: compact_kernel, whose outputs these are, bit for bit) with K1 folded
+// in: a workgroup of BIN = 1024 staged rows writes its visible ones -- one contiguous range of compact rows -- and, while
+// it still holds them in registers, runs K1's query on them.  Frame calls only (gs_project_fwd_ex with a GsMapBinPlan).
+__global__ __launch_bounds__(BIN) void compact_bin_kernel(GsCompactArgs c, MapArgs a, RegionGrid rg, int num_wg,
+                                                          int* region_of, int* part, int* touched_blocks,
+                                                          int* block_start) {
+  __shared__ int s_hist[MAX_REGIONS];
+  __shared__ int s_cnt[16];
+  __shared__ int s_before[16];
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
+  const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
+  const float4* st_rows = static_cast<const float4*>(c.st_rows);
+  float4 r0 = make_float4(0, 0, 0, 0), r1 = r0;
+  bool vis = false;
+  if (i < c.n) {
+    r0 = st_rows[2 * i];
+    r1 = st_rows[2 * i + 1];
+    vis = r1.w != 0.0f;
+  }
+  const uint64_t b = __ballot(vis);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) s_cnt[wave] = __popcll(b);
+  const int first_small = int(blockIdx.x) * (BIN / 256);  // the projection pass counted per 256 Gaussians
+  int before = 0;
+  if (!c.block_offsets) {
+    for (int j = threadIdx.x; j < first_small; j += BIN) before += c.block_counts[j];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if (lane == 0) s_before[wave] = before;
+  }
+  __syncthreads();
+  int base = 0;
+  if (c.block_offsets) {
+    base = first_small < c.num_blocks ? c.block_offsets[first_small] : 0;
+  } else {
+#pragma unroll
+    for (int w = 0; w < 16; ++w) base += s_before[w];
+  }
+  const int first = base;
+  int mine_total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base += w < wave ? s_cnt[w] : 0;
+    mine_total += s_cnt[w];
+  }
+  bool binned = false;
+  if (i < c.n) {
+    int slot = -1;
+    if (vis) {
+      slot = base + __popcll(b & ((1ull << lane) - 1ull));
+      float* p = c.points + int64_t(slot) * 7;
+      p[0] = r0.x; p[1] = r0.y; p[2] = r0.z; p[3] = r0.w; p[4] = r1.x; p[5] = r1.y; p[6] = r1.z;
+      c.depth[slot] = r1.w;
+      if (c.depth_feat) {
+        c.depth_feat[int64_t(slot) * c.depth_feat_stride] = r1.w;
+        c.depth_feat[int64_t(slot) * c.depth_feat_stride + 1] = r1.w * r1.w;
+      }
+      const float inv_d = __fdiv_rn(1.0f, r1.w);  // the sort key: fixed f32 op order
+      c.ndc[slot] = 1.0f - __fdiv_rn(inv_d - c.inv_far, c.ndc_denom);
+      c.indexes[slot] = i;
+      // K1 on the row in registers
+      const float g[7] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
+      const GridQuery q = grid_query(g, a.Wp, a.Hp, a.tile_size, a.thr);
+      const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
+      const int r = any ? region_of_gaussian(g, a, rg) : -1;
+      region_of[slot] = r;
+      if (r >= 0) atomicAdd(&s_hist[r], 1);
+      binned = r >= 0;
+    }
+    c.slot_of[i] = slot;
+  }
+  const int touched = __syncthreads_count(binned);
+  if (threadIdx.x == 0) {
+    touched_blocks[blockIdx.x] = touched;
+    block_start[blockIdx.x] = first;
+    if (int(blockIdx.x) == num_wg - 1) {
+      block_start[num_wg] = first + mine_total;
+      *c.num_visible = first + mine_total;
+    }
+  }
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
+  if (c.zero_rows) {  // the frame's gradient rows, cleared by the pass that streams the V rows anyway (project.hip)
+    float4* dst = static_cast<float4*>(c.zero_rows) + int64_t(first) * c.zero_row_v4;
+    for (int e = threadIdx.x; e < mine_total * c.zero_row_v4; e += BIN) dst[e] = make_float4(0, 0, 0, 0);
   }
 }
 
@@ -1120,6 +1215,7 @@ struct MapScratch {
   int* chunk_start;
   QueryCache* qcache;
   int* touched_blocks;  // per 1024-row workgroup of the binning pass: rows that entered the ordering
+  int* block_start;     // rows of workgroup b of the binning pass: [block_start[b], block_start[b + 1])
 };
 // part[region][workgroup]; the region count is bounded by the tile count and by MAX_REGIONS
 int64_t part_entries(int64_t v, int64_t num_tiles) {
@@ -1140,6 +1236,7 @@ MapScratch carve(void* scratch, int64_t v, int64_t num_tiles) {
   m.part = take(part_entries(v, num_tiles) * 4);
   m.qcache = reinterpret_cast<QueryCache*>(take(v * int64_t(sizeof(QueryCache))));
   m.touched_blocks = take((gs_div_up(v > 0 ? v : 1, BIN) + 1) * 4);
+  m.block_start = take((gs_div_up(v > 0 ? v : 1, BIN) + 1) * 4);
   return m;
 }
 RegionGrid make_grid(const MapArgs& a) {
@@ -1159,7 +1256,7 @@ RegionGrid make_grid(const MapArgs& a) {
 extern "C" int64_t gs_map_scratch_bytes(int64_t v, int64_t num_tiles) {
   return gs_align_up(num_tiles * 4, 256) * 2 + gs_align_up(v * 4, 256) * 2 +
          gs_align_up((MAX_REGIONS + 1) * 4, 256) * 3 + gs_align_up(part_entries(v, num_tiles) * 4, 256) +
-         gs_align_up(v * int64_t(sizeof(QueryCache)), 256) + gs_align_up((gs_div_up(v > 0 ? v : 1, BIN) + 1) * 4, 256);
+         gs_align_up(v * int64_t(sizeof(QueryCache)), 256) + 2 * gs_align_up((gs_div_up(v > 0 ? v : 1, BIN) + 1) * 4, 256);
 }
 
 extern "C" int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles) {
@@ -1170,13 +1267,12 @@ extern "C" int64_t gs_map_touched_offset(int64_t v, int64_t num_tiles) {
 namespace {
 // ascending list of the rows with region_of >= 0: a stable compaction on the per-workgroup counts the binning pass
 // left (every workgroup adds up the counts in front of it, as the projection's compaction does)
-__global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const int* v_dev, const int* region_of,
+__global__ __launch_bounds__(1024) void touched_write_kernel(const int* block_start, const int* region_of,
                                                              const int* block_counts, int* touched, int* count_out) {
   __shared__ int s_wave[16];
   __shared__ int s_before[16];
-  const int64_t live = v_dev ? (int64_t(*v_dev) < v ? int64_t(*v_dev) : v) : v;
-  const int64_t i = int64_t(blockIdx.x) * 1024 + threadIdx.x;
-  const bool flag = i < live && region_of[i] >= 0;
+  const int i = block_start[blockIdx.x] + int(threadIdx.x);  // the binning pass's own rows (ascending over workgroups)
+  const bool flag = i < block_start[blockIdx.x + 1] && region_of[i] >= 0;
   const uint64_t b = __ballot(flag);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) s_wave[wave] = __popcll(b);
@@ -1188,7 +1284,7 @@ __global__ __launch_bounds__(1024) void touched_write_kernel(int64_t v, const in
   int base = 0;
   for (int w = 0; w < 16; ++w) base += s_before[w];
   for (int w = 0; w < wave; ++w) base += s_wave[w];
-  if (flag) touched[base + __popcll(b & ((1ull << lane) - 1ull))] = int(i);
+  if (flag) touched[base + __popcll(b & ((1ull << lane) - 1ull))] = i;
   if (count_out && blockIdx.x == gridDim.x - 1 && threadIdx.x == 1023) {  // the last thread knows the total
     int total = base + __popcll(b);
     for (int w = wave + 1; w < 16; ++w) total += s_wave[w];  // (wave 15 here: nothing behind it)
@@ -1259,8 +1355,8 @@ extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_
   GS_REQUIRE(touched_out, GS_ERR_INVALID_ARGUMENT, "gs_map_touched_list: touched_out is NULL");
   const MapScratch m = carve(const_cast<void*>(scratch), v, num_tiles);
   const int* block_counts = m.touched_blocks;  // BIN = 1024 rows per workgroup of the binning pass
-  hipLaunchKernelGGL(touched_write_kernel, dim3(nb), dim3(1024), 0, s, v, v_dev, m.region_of, block_counts, touched_out,
-                     count_out);
+  hipLaunchKernelGGL(touched_write_kernel, dim3(nb), dim3(1024), 0, s, m.block_start, m.region_of, block_counts,
+                     touched_out, count_out);
   if (owner_counts) {
     GS_REQUIRE(!owned_rows || (owner >= 0 && owner < world), GS_ERR_INVALID_ARGUMENT,
                "gs_map_touched_list: owned_rows needs the owner's rank");
@@ -1271,10 +1367,37 @@ extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_
   return GS_OK;
 }
 
+int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* stream) {
+  MapArgs a;
+  if (int rc = fill_args(a, c->n, c->points, nullptr, plan->width, plan->height, plan->cfg, 0, plan->shard)) return rc;
+  GS_REQUIRE(a.sh.local_rows > 0 && c->n > 0, GS_ERR_INVALID_ARGUMENT, "gs_map_compact_bin: nothing to bin");
+  const int num_tiles = a.tiles_wide * a.sh.local_rows;
+  GS_REQUIRE(plan->scratch && plan->scratch_bytes >= gs_map_scratch_bytes(c->n, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_map_compact_bin: mapper scratch %lld < %lld bytes", (long long)plan->scratch_bytes,
+             (long long)gs_map_scratch_bytes(c->n, num_tiles));
+  const RegionGrid rg = make_grid(a);
+  GS_REQUIRE(rg.num_regions <= MAX_REGIONS, GS_ERR_UNSUPPORTED, "gs_map_compact_bin: %d regions", rg.num_regions);
+  const MapScratch m = carve(plan->scratch, c->n, num_tiles);
+  const unsigned vb = unsigned(gs_div_up(c->n, BIN));
+  hipLaunchKernelGGL(compact_bin_kernel, dim3(vb), dim3(BIN), 0, static_cast<hipStream_t>(stream), *c, a, rg, int(vb),
+                     m.region_of, m.part, m.touched_blocks, m.block_start);
+  GS_CHECK_LAUNCH("gs_map_compact_bin");
+  return GS_OK;
+}
+
 extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                               const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges,
                               int32_t* counts_out, int32_t* counts_host, int32_t* tile_order,
                               const GsRowShard* shard, void* scratch, int64_t scratch_bytes, void* stream) {
+  return gs_map_prepare_ex(v, v_dev, points, width, height, cfg, k_capacity, tile_ranges, counts_out, counts_host,
+                           tile_order, shard, scratch, scratch_bytes, 0, stream);
+}
+
+// binned != 0: gs_map_compact_bin has filled region_of / part / touched_blocks / block_start of `scratch` already
+int gs_map_prepare_ex(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
+                      const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
+                      int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,
+                      int64_t scratch_bytes, int binned, void* stream) {
   MapArgs a;
   if (int rc = fill_args(a, v, points, nullptr, width, height, cfg, 0, shard)) return rc;
   a.v_dev = v_dev;
@@ -1300,13 +1423,15 @@ extern "C" int gs_map_prepare(int64_t v, const int32_t* v_dev, const float* poin
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
     const unsigned vb = unsigned(gs_div_up(v, BIN));
-    hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part, m.touched_blocks);
+    if (!binned)
+      hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part,
+                         m.touched_blocks, m.block_start);
     hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
                        m.region_count, hist, num_tiles);
     hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,
                        m.chunk_start);
-    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part,
-                       m.region_start, m.order);
+    hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(BIN), 0, s, rg, int(vb), m.region_of, m.part,
+                       m.region_start, m.block_start, m.order);
     // one workgroup per chunk of <= CHUNK Gaussians of one region; surplus workgroups exit at once
     hipLaunchKernelGGL(count_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
                        size_t(rg.win) * rg.win * 4, s, a, rg, m.order,

@@ -428,17 +428,20 @@ extern "C" int gs_project_fwd(int64_t n, const float* position, const float* log
                               int64_t scratch_bytes, void* stream) {
   return gs_project_fwd_ex(n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
                            near_plane, far_plane, cfg, points, depth, ndc_depth, indexes, slot_of, num_visible,
-                           depth_features, depth_features_stride, camera_pos, scratch, scratch_bytes, nullptr, 0, stream);
+                           depth_features, depth_features_stride, camera_pos, scratch, scratch_bytes, nullptr, 0, nullptr,
+                           stream);
 }
 
 // gs_project_fwd + (library-internal, used by gs_frame_fwd) zero_rows: a (V, zero_row_floats) buffer, 16-byte aligned
-// rows, whose first V rows the compaction pass zero-fills
+// rows, whose first V rows the compaction pass zero-fills; bin: the compaction pass also does the tile mapper's region
+// binning (gs_common.h: GsMapBinPlan)
 int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling, const float* rotation,
                       const float* alpha_logit, const float* T_camera_world, const float* projection, int32_t width,
                       int32_t height, double near_plane, double far_plane, const GsRasterConfig* cfg, float* points,
                       float* depth, float* ndc_depth, int64_t* indexes, int32_t* slot_of, int32_t* num_visible,
                       float* depth_features, int32_t depth_features_stride, float* camera_pos, void* scratch,
-                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, void* stream) {
+                      int64_t scratch_bytes, float* zero_rows, int32_t zero_row_floats, const GsMapBinPlan* bin,
+                      void* stream) {
   ProjArgs a;
   if (int rc = fill(a, n, position, log_scaling, rotation, alpha_logit, T_camera_world, projection, width, height,
                     near_plane, far_plane, cfg))
@@ -468,6 +471,15 @@ int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling
   const bool self_offsets = nb <= 16384;
   if (!self_offsets)
     if (int rc = gs_full_cumsum_i32(nb, counts, offsets, scan_scratch, gs_cumsum_scratch_bytes(nb), s)) return rc;
+  if (bin) {
+    GsCompactArgs c;
+    c.n = n; c.st_rows = st_rows; c.block_offsets = self_offsets ? nullptr : offsets; c.block_counts = counts;
+    c.num_blocks = nb; c.inv_far = a.inv_far; c.ndc_denom = a.ndc_denom;
+    c.points = points; c.depth = depth; c.ndc = ndc_depth; c.indexes = indexes; c.slot_of = slot_of;
+    c.num_visible = num_visible; c.depth_feat = depth_features; c.depth_feat_stride = depth_features_stride;
+    c.zero_rows = zero_rows; c.zero_row_v4 = zero_row_floats / 4;
+    return gs_map_compact_bin(bin, &c, stream);
+  }
   hipLaunchKernelGGL(compact_kernel, dim3(nb), dim3(256), 0, s, n, st_rows, self_offsets ? nullptr : offsets, counts, nb, a.inv_far, a.ndc_denom,
                      points, depth, ndc_depth, indexes, slot_of, num_visible, depth_features, depth_features_stride,
                      reinterpret_cast<float4*>(zero_rows), zero_row_floats / 4);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# as ab_lib.sh, printing one named stage:  tools/ab_stage.sh STAGE lib_a.so lib_b.so ...
+# as ab_lib.sh, printing named stages:  tools/ab_stage.sh STAGE[,STAGE...] lib_a.so lib_b.so ...
 stage=$1; shift
 for round in 1 2 3; do
   for lib in "$@"; do
@@ -8,7 +8,7 @@ import sys, json
 text = sys.stdin.read()
 try:
     d = json.loads(text); s = d['stages_ms_untimed_pass']
-    print('$lib', d['ms_per_step'], '$stage', s.get('$stage'))
+    print('$lib', d['ms_per_step'], ' '.join(f'{k} {s.get(k)}' for k in '$stage'.split(',')))
 except Exception as e:
     print('$lib', 'bench failed:', open('gpurun_out/ab_err.txt').read()[-300:])"
   done
