@@ -105,6 +105,9 @@ struct BwdShape {
 // + 2 result writes more per (tile, splat) put the CU's LDS array at ~170 of the ~200 cycles four SIMDs spend on a
 // splat -- the reduction leaves the VALU port only to queue at the LDS.  (v1, one pass with 8 rows, also costs a wave of
 // occupancy: 1.167 vs 1.137 ms per frame.)
+#ifndef GS_BWD_FETCH_AHEAD
+#define GS_BWD_FETCH_AHEAD 1
+#endif
 #ifndef GS_BWD_LDS_REDUCE
 #define GS_BWD_LDS_REDUCE 0
 #endif
@@ -227,12 +230,12 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
     for (int c = 0; c < NACC; ++c) s_acc[lane][c] = 0.0f;
     __syncthreads();
 
-    for (int j = 0; j < cnt; ++j) {
-      const float4 g0v = s_geo[j][0], g1v = s_geo[j][1];
-      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
-      float4 g2v = make_float4(0, 0, 0, 0);
+    float4 g0v, g1v, g2v = make_float4(0, 0, 0, 0);
+    float feat[FP];
+    auto fetch_record = [&](int j) {
+      g0v = s_geo[j][0];
+      g1v = s_geo[j][1];
       if (FULL) g2v = s_geo[j][2];
-      float feat[FP];
 #pragma unroll
       for (int q = 0; q < REC_V4 - GEO_V4; ++q) {
         const float4 fq = s_geo[j][GEO_V4 + q];
@@ -241,6 +244,11 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         for (int k = 0; k < 4; ++k)
           if (4 * q + k < FP) feat[4 * q + k] = fv[k];
       }
+    };
+    if (GS_BWD_FETCH_AHEAD) fetch_record(0);
+    for (int j = 0; j < cnt; ++j) {
+      if (!GS_BWD_FETCH_AHEAD) fetch_record(j);
+      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
 
       float S[NS], gf[FP];
 #pragma unroll
@@ -360,6 +368,10 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         asm("v_fma_f32 %0, -%1, %2, %0" : "+v"(R[b]) : "v"(dot), "v"(w));
       }
 
+      // The record's registers are dead from here to the end of the iteration: the next splat's record is fetched into
+      // them NOW, so that its LDS latency passes under the reduction below instead of in front of the next splat's
+      // first instruction (no second register set, no copies).
+      if (GS_BWD_FETCH_AHEAD) fetch_record(min(j + 1, 63));
       // reduce over the wave only if some pixel took a gradient (backward.py:204)
       if (any_grad) {
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
