@@ -141,6 +141,11 @@ struct GsCompactArgs {
   void* zero_rows; int zero_row_v4;  // float4 units per row
 };
 int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* stream);
+// experiment (GS_PROJECT_ONE_PASS): projection + cull + compaction + binning in ONE kernel with a decoupled look-back
+// (mapper.hip); pa = project.hip's filled gs_proj::ProjArgs, lookback = gs_map_one_pass_scratch_bytes(n) bytes
+int64_t gs_map_one_pass_scratch_bytes(int64_t n);
+int gs_map_project_compact_bin(const GsMapBinPlan* plan, const void* pa, const GsCompactArgs* c, float* camera_pos,
+                               void* lookback, void* stream);
 int gs_map_prepare_ex(int64_t v, const int32_t* v_dev, const float* points, int32_t width, int32_t height,
                       const GsRasterConfig* cfg, int64_t k_capacity, int32_t* tile_ranges, int32_t* counts_out,
                       int32_t* counts_host, int32_t* tile_order, const GsRowShard* shard, void* scratch,

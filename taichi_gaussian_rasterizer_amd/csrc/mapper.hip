@@ -31,6 +31,7 @@
 
 #include "gs_common.h"
 #include "../../include/gs_detmath.h"
+#include "project_math.h"
 
 namespace {
 
@@ -522,6 +523,173 @@ __global__ __launch_bounds__(BIN) void compact_bin_kernel(GsCompactArgs c, MapAr
   }
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
   if (c.zero_rows) {  // the frame's gradient rows, cleared by the pass that streams the V rows anyway (project.hip)
+    float4* dst = static_cast<float4*>(c.zero_rows) + int64_t(first) * c.zero_row_v4;
+    for (int e = threadIdx.x; e < mine_total * c.zero_row_v4; e += BIN) dst[e] = make_float4(0, 0, 0, 0);
+  }
+}
+
+// One pass: projection + cull + stable compaction + K1 (experiment, GS_PROJECT_ONE_PASS).  The visible
+// counts of the workgroups in front are not read from a counting pass but found by a decoupled look-back over one
+// 64-bit descriptor per workgroup -- flag << 32 | count, flag 1 = this workgroup's own count ("aggregate"), 2 = the count
+// of everything up to and including it ("prefix") -- written and polled with agent-scope atomics (they bypass the
+// XCD-local L2).  Workgroup ids are tickets drawn from an atomic counter, so every predecessor a workgroup polls has
+// started before it: resident workgroups only ever wait for resident or finished ones.  The polling is bounded: a
+// workgroup that does not see its predecessors after LOOKBACK_POLLS rounds gives up, sets the failure word and writes
+// nothing (the experiment does not surface that word to the caller; a shipped version would poison V with it).
+// Measured at C3 (profiles/r3/ab_project_one_pass.txt): bit-identical outputs, gs_project_fwd 56 us against 48 us for
+// project_kernel + compact_bin_kernel -- the first cohort of resident workgroups resolves its look-back in ~8 serial
+// windows of 64 while nothing is written.  Variant 2 (count, then project again: ab_project_count_then_recompute.txt):
+// 64 us -- the projection's arithmetic (IEEE divisions, square roots, exp, the exact log) is not free next to its 44
+// bytes.  Neither is used.
+constexpr int LOOKBACK_POLLS = 1 << 18;
+constexpr unsigned long long LB_AGGREGATE = 1ull << 32, LB_PREFIX = 2ull << 32;
+
+// (variant 2, LOOKBACK = false: a counting pass -- the projection, nothing written but one count per workgroup -- in
+// front, and this kernel adds up the counts of the workgroups before it: the projection is evaluated twice, the 32-byte
+// staging rows are neither written nor read.)
+__global__ __launch_bounds__(BIN) void project_count_kernel(gs_proj::ProjArgs pa, int* counts) {
+  __shared__ int s_cnt[16];
+  const int64_t i = int64_t(blockIdx.x) * BIN + threadIdx.x;
+  bool vis = false;
+  if (i < pa.n) {
+    const gs_proj::Cam cam = gs_proj::load_cam(pa.T44, pa.proj);
+    gs_proj::Fwd f;
+    gs_proj::forward(pa, cam, i, f);
+    vis = gs_proj::visible(pa, f);
+  }
+  const uint64_t b = __ballot(vis);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += s_cnt[w];
+    counts[blockIdx.x] = t;
+  }
+}
+
+template <bool LOOKBACK>
+__global__ __launch_bounds__(BIN) void project_compact_bin_kernel(gs_proj::ProjArgs pa, GsCompactArgs c, MapArgs a,
+                                                                  RegionGrid rg, int num_wg, int* region_of, int* part,
+                                                                  int* touched_blocks, int* block_start,
+                                                                  unsigned long long* desc, int* ticket, int* failed,
+                                                                  float* cam_out) {
+  __shared__ int s_hist[MAX_REGIONS];
+  __shared__ int s_cnt[16];
+  __shared__ int s_scalar[2];
+  __shared__ int s_before[16];
+  if (LOOKBACK && threadIdx.x == 0) s_scalar[0] = atomicAdd(ticket, 1);
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
+  __syncthreads();
+  const int blk = LOOKBACK ? s_scalar[0] : int(blockIdx.x);
+  if (blk >= num_wg) return;  // (cannot happen: the grid is num_wg workgroups)
+  if (cam_out && blk == 0 && threadIdx.x == 0) gs_proj::camera_position(pa.T44, cam_out);
+  const int64_t i = int64_t(blk) * BIN + threadIdx.x;
+  gs_proj::Fwd f;
+  bool vis = false;
+  if (i < pa.n) {
+    const gs_proj::Cam cam = gs_proj::load_cam(pa.T44, pa.proj);
+    gs_proj::forward(pa, cam, i, f);
+    vis = gs_proj::visible(pa, f);
+  }
+  const uint64_t b = __ballot(vis);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) s_cnt[wave] = __popcll(b);
+  if (!LOOKBACK) {
+    int before = 0;
+    for (int j = threadIdx.x; j < blk; j += BIN) before += c.block_counts[j];
+    for (int off = 32; off > 0; off >>= 1) before += __shfl_xor(before, off);
+    if (lane == 0) s_before[wave] = before;
+  }
+  __syncthreads();
+  int mine_total = 0, base = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    base += w < wave ? s_cnt[w] : 0;
+    mine_total += s_cnt[w];
+  }
+  if (!LOOKBACK && threadIdx.x == 0) {
+    int before = 0;
+    for (int w = 0; w < 16; ++w) before += s_before[w];
+    s_scalar[0] = before;
+    s_scalar[1] = 1;
+  }
+  if (LOOKBACK && wave == 0) {
+    if (lane == 0)
+      __hip_atomic_store(desc + blk, (blk == 0 ? LB_PREFIX : LB_AGGREGATE) | (unsigned long long)(unsigned)mine_total,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int before = 0;
+    bool ok = true;
+    for (int look = blk - 1; look >= 0; look -= 64) {
+      const int j = look - lane;  // lane 0 = the nearest predecessor
+      unsigned long long d = LB_PREFIX;  // in front of workgroup 0: nothing
+      int polls = 0;
+      if (j >= 0) d = __hip_atomic_load(desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__ballot((d >> 32) == 0ull) != 0ull) {
+        if (++polls > LOOKBACK_POLLS) { ok = false; break; }
+        __builtin_amdgcn_s_sleep(2);
+        if ((d >> 32) == 0ull) d = __hip_atomic_load(desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (!ok) break;
+      const uint64_t prefixes = __ballot((d >> 32) == 2ull);
+      const int first = prefixes != 0ull ? __ffsll(static_cast<unsigned long long>(prefixes)) - 1 : 63;
+      int v = lane <= first ? int(unsigned(d)) : 0;
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+      before += v;
+      if (prefixes != 0ull) break;
+    }
+    if (lane == 0) {
+      if (ok && blk > 0)
+        __hip_atomic_store(desc + blk, LB_PREFIX | (unsigned long long)(unsigned)(before + mine_total), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      if (!ok) {  // successors must not wait for this one for ever either
+        __hip_atomic_store(desc + blk, LB_PREFIX, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *failed = 1;
+      }
+      s_scalar[0] = before;
+      s_scalar[1] = ok ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  const int first = s_scalar[0];
+  const bool ok = s_scalar[1] != 0;
+  base += first;
+  bool binned = false;
+  if (i < pa.n && ok) {
+    int slot = -1;
+    if (vis && base + __popcll(b & ((1ull << lane) - 1ull)) < c.n) {  // (always, unless the two passes disagreed)
+      slot = base + __popcll(b & ((1ull << lane) - 1ull));
+      const float z = f.cam[2];
+      float* p = c.points + int64_t(slot) * 7;
+      p[0] = f.u; p[1] = f.v; p[2] = f.ax; p[3] = f.ay; p[4] = f.s1; p[5] = f.s2; p[6] = f.alpha;
+      c.depth[slot] = z;
+      if (c.depth_feat) {
+        c.depth_feat[int64_t(slot) * c.depth_feat_stride] = z;
+        c.depth_feat[int64_t(slot) * c.depth_feat_stride + 1] = z * z;
+      }
+      const float inv_d = __fdiv_rn(1.0f, z);
+      c.ndc[slot] = 1.0f - __fdiv_rn(inv_d - c.inv_far, c.ndc_denom);
+      c.indexes[slot] = i;
+      const float g[7] = {f.u, f.v, f.ax, f.ay, f.s1, f.s2, f.alpha};
+      const GridQuery q = grid_query(g, a.Wp, a.Hp, a.tile_size, a.thr);
+      const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
+      const int r = any ? region_of_gaussian(g, a, rg) : -1;
+      region_of[slot] = r;
+      if (r >= 0) atomicAdd(&s_hist[r], 1);
+      binned = r >= 0;
+    }
+    c.slot_of[i] = slot;
+  }
+  const int touched = __syncthreads_count(binned);
+  if (threadIdx.x == 0) {
+    touched_blocks[blk] = touched;
+    block_start[blk] = first;
+    if (blk == num_wg - 1) {
+      block_start[num_wg] = first + mine_total;
+      *c.num_visible = first + mine_total;
+    }
+  }
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blk] = s_hist[r];
+  if (c.zero_rows && ok) {
     float4* dst = static_cast<float4*>(c.zero_rows) + int64_t(first) * c.zero_row_v4;
     for (int e = threadIdx.x; e < mine_total * c.zero_row_v4; e += BIN) dst[e] = make_float4(0, 0, 0, 0);
   }
@@ -1382,6 +1550,49 @@ int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* s
   hipLaunchKernelGGL(compact_bin_kernel, dim3(vb), dim3(BIN), 0, static_cast<hipStream_t>(stream), *c, a, rg, int(vb),
                      m.region_of, m.part, m.touched_blocks, m.block_start);
   GS_CHECK_LAUNCH("gs_map_compact_bin");
+  return GS_OK;
+}
+
+int64_t gs_map_one_pass_scratch_bytes(int64_t n) { return gs_align_up((gs_div_up(n > 0 ? n : 1, BIN) + 2) * 8, 256); }
+
+// one pass: `pa` is project.hip's filled gs_proj::ProjArgs; lookback: gs_map_one_pass_scratch_bytes(n) bytes
+int gs_map_project_compact_bin(const GsMapBinPlan* plan, const void* pa, const GsCompactArgs* c, float* camera_pos,
+                               void* lookback, void* stream) {
+  MapArgs a;
+  if (int rc = fill_args(a, c->n, c->points, nullptr, plan->width, plan->height, plan->cfg, 0, plan->shard)) return rc;
+  GS_REQUIRE(a.sh.local_rows > 0 && c->n > 0 && lookback, GS_ERR_INVALID_ARGUMENT, "gs_map_project_compact_bin: nothing to bin");
+  const int num_tiles = a.tiles_wide * a.sh.local_rows;
+  GS_REQUIRE(plan->scratch && plan->scratch_bytes >= gs_map_scratch_bytes(c->n, num_tiles), GS_ERR_SCRATCH_TOO_SMALL,
+             "gs_map_project_compact_bin: mapper scratch %lld < %lld bytes", (long long)plan->scratch_bytes,
+             (long long)gs_map_scratch_bytes(c->n, num_tiles));
+  const RegionGrid rg = make_grid(a);
+  GS_REQUIRE(rg.num_regions <= MAX_REGIONS, GS_ERR_UNSUPPORTED, "gs_map_project_compact_bin: %d regions", rg.num_regions);
+  const MapScratch m = carve(plan->scratch, c->n, num_tiles);
+  const unsigned vb = unsigned(gs_div_up(c->n, BIN));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (c->block_offsets == reinterpret_cast<const int*>(1)) {  // variant 2: count, then project again
+    GsCompactArgs c2 = *c;
+    c2.block_offsets = nullptr;
+    c2.block_counts = static_cast<int*>(lookback);
+    hipLaunchKernelGGL(project_count_kernel, dim3(vb), dim3(BIN), 0, s, *static_cast<const gs_proj::ProjArgs*>(pa),
+                       static_cast<int*>(lookback));
+    hipLaunchKernelGGL(project_compact_bin_kernel<false>, dim3(vb), dim3(BIN), 0, s,
+                       *static_cast<const gs_proj::ProjArgs*>(pa), c2, a, rg, int(vb), m.region_of, m.part,
+                       m.touched_blocks, m.block_start, nullptr, nullptr, nullptr, camera_pos);
+    GS_CHECK_LAUNCH("gs_map_project_compact_bin");
+    return GS_OK;
+  }
+  // descriptors, then the ticket counter and the failure flag
+  if (hipMemsetAsync(lookback, 0, size_t(gs_map_one_pass_scratch_bytes(c->n)), s) != hipSuccess) {
+    gs_set_error("gs_map_project_compact_bin: hipMemsetAsync failed");
+    return GS_ERR_LAUNCH;
+  }
+  unsigned long long* desc = static_cast<unsigned long long*>(lookback);
+  int* ticket = reinterpret_cast<int*>(desc + vb);
+  hipLaunchKernelGGL(project_compact_bin_kernel<true>, dim3(vb), dim3(BIN), 0, s,
+                     *static_cast<const gs_proj::ProjArgs*>(pa), *c, a, rg, int(vb), m.region_of, m.part,
+                     m.touched_blocks, m.block_start, desc, ticket, ticket + 1, camera_pos);
+  GS_CHECK_LAUNCH("gs_map_project_compact_bin");
   return GS_OK;
 }
 
