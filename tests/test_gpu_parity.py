@@ -876,6 +876,31 @@ def test_fused_frame_equals_composed_operators(depth_mode, heur, frame_path):
             pu.assert_grad_close(r.point_heuristic, r2.point_heuristic, "heuristic", tol=1e-4)
 
 
+@pytest.mark.parametrize("n", [1, 63, 1023, 1024, 1025, 2049, 3072])
+def test_fused_frame_at_binning_workgroup_edges(n, frame_path):
+    """the frame calls fold the mapper's region binning into the projection's compaction pass, 1024 staged rows per
+    workgroup (mapper.hip: compact_bin_kernel); counts at and around multiples of that must give the composed operators'
+    frame bit for bit"""
+    from taichi_gaussian_rasterizer_amd.renderer import render_projected
+    size = (160, 96)
+    cfg = RasterConfig()
+    g, camera = scenes.benchmark_scene(n, size, sh_degree=1, seed=100 + n)
+    cam = camera.to(device=DEV)
+    a = g.to(DEV).requires_grad_(True)
+    r = gs.render_gaussians(a, cam, cfg, use_sh=True)
+    b = g.to(DEV).requires_grad_(True)
+    g2d, depths, idx, ndc = hip_proj.project_with_ndc(*b.shape_tensors(), cam.T_camera_world, cam.projection,
+                                                      cam.image_size, cam.depth_range, cfg)
+    feats = gs.evaluate_sh_at(b.feature, b.position.detach(), idx, cam.camera_position)
+    r2 = render_projected(idx, g2d, feats, depths, cam, cfg, ndc_depths=ndc)
+    assert torch.equal(r.points_in_view, r2.points_in_view) and torch.equal(r.gaussians2d, r2.gaussians2d)
+    assert torch.equal(r.image, r2.image) and torch.equal(r.image_weight, r2.image_weight)
+    r.image.sum().backward()
+    r2.image.sum().backward()
+    for k, t in a.items():
+        pu.assert_grad_close(t.grad, getattr(b, k).grad, f"grad {k}", tol=1e-3)
+
+
 @pytest.mark.parametrize("depth_mode", [False, True])
 def test_fused_frame_gradients_through_projected_splats(depth_mode, frame_path):
     """a loss that also reads `gaussians2d` and `point_depth` (a regulariser on the projected splats): the fused
