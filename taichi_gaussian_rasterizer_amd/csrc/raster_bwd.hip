@@ -146,8 +146,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   for (int b = 0; b < NB; ++b) {
     const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
     const bool inb = X < a.W && Y < a.H;
-    Xf[b] = float(X) + 0.5f;
-    Yf[b] = float(Y) + 0.5f;
+    // lean modes: pixel centres relative to the wave's origin, as in the forward (raster_fwd.hip)
+    Xf[b] = FULL ? float(X) + 0.5f : float((b & 1) * 8 + lx) + 0.5f;
+    Yf[b] = FULL ? float(Y) + 0.5f : float((b >> 1) * 8 + ly) + 0.5f;
     Tr[b] = inb ? 1.0f : 0.0f;  // backward.py:99-112: out-of-image pixels start saturated
     R[b] = 0.0f;
 #pragma unroll
@@ -212,7 +213,10 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         s_geo[lane][0] = make_float4(mx, my, p[4], p[5]);
         s_geo[lane][1] = make_float4(0.5f * isx, 0.5f * isy, al, __int_as_float(mask));
       } else {
-        s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+        // lean: tx = A . (X - origin) + A . (origin - m), the second term formed here (the forward's expression)
+        const float ox = float(x0) - mx, oy = float(y0) - my;
+        if (FULL) s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+        else s_geo[lane][0] = make_float4(__builtin_fmaf(Ax, ox, Ay * oy), __builtin_fmaf(Bx, ox, By * oy), Ax, Ay);
         // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
         s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
       }
@@ -260,7 +264,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         if (!(mask & (1 << b))) continue;  // scalar branch
-        const float dx = Xf[b] - g0v.x, dy = Yf[b] - g0v.y;
+        const float dx = FULL ? Xf[b] - g0v.x : 0.0f, dy = FULL ? Yf[b] - g0v.y : 0.0f;
         float p, tx = 0, ty = 0;
         float dmx = 0, dmy = 0, dax = 0, day = 0, dsx = 0, dsy = 0;
         float Px = 0, Py = 0;  // antialias: d pdf / d (ux, uy), the splat-frame gradient the mean and axis terms share
@@ -291,8 +295,8 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           day = __builtin_fmaf(Px, dy, -(Py * dx));
           // dmx, dmy: the wave totals of aag Px, aag Py are rotated out of the frame once per splat (epilogue)
         } else {
-          tx = dx * g0v.z + dy * g0v.w;
-          ty = dx * g1v.x + dy * g1v.y;
+          tx = FULL ? dx * g0v.z + dy * g0v.w : __builtin_fmaf(g0v.z, Xf[b], __builtin_fmaf(g0v.w, Yf[b], g0v.x));
+          ty = FULL ? dx * g1v.x + dy * g1v.y : __builtin_fmaf(g1v.x, Xf[b], __builtin_fmaf(g1v.y, Yf[b], g0v.y));
           // lean: the record carries -log2(opacity), p is alpha itself (same expression as the forward: same bits)
           p = FULL ? gs_exp2_fast(-0.72134752044448170f * (tx * tx + ty * ty))
                    : gs_exp2_fast(-__builtin_fmaf(ty, ty, __builtin_fmaf(tx, tx, g1v.z)));

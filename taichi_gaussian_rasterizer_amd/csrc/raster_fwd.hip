@@ -97,8 +97,9 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
   for (int b = 0; b < NB; ++b) {
     const int X = x0 + (b & 1) * 8 + lx, Y = y0 + (b >> 1) * 8 + ly;
     inb[b] = X < a.W && Y < a.H;
-    Xf[b] = float(X) + 0.5f;
-    Yf[b] = float(Y) + 0.5f;
+    // lean modes: pixel centres relative to the wave's origin (see the staging below); general mode: absolute
+    Xf[b] = FULL ? float(X) + 0.5f : float((b & 1) * 8 + lx) + 0.5f;
+    Yf[b] = FULL ? float(Y) + 0.5f : float((b >> 1) * 8 + ly) + 0.5f;
     Tr[b] = inb[b] ? 1.0f : 0.0f;  // forward.py:53-54: out-of-image pixels start with W = 1
     done[b] = false;
 #pragma unroll
@@ -149,7 +150,13 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, __log2f(al * a.inv_thr), float(x0) + 0.5f - mx,
                                      float(y0) + 0.5f - my);
       }
-      s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+      // Lean modes: the ellipse-frame coordinates of a pixel are tx = A . (X - m) = A . (X - origin) + A . (origin - m):
+      // the second term is formed once per (region, splat) here, and a pixel's tx is two fma on its origin-relative
+      // centre (|X - origin| < 16: no cancellation beyond what X - m has) instead of two subtractions, a multiply and
+      // an fma.  The backward uses the same expression: same bits, same hit / miss per pixel.
+      const float ox = float(x0) - mx, oy = float(y0) - my;
+      if (FULL) s_geo[lane][0] = make_float4(mx, my, Ax, Ay);
+      else s_geo[lane][0] = make_float4(__builtin_fmaf(Ax, ox, Ay * oy), __builtin_fmaf(Bx, ox, By * oy), Ax, Ay);
       // lean modes carry -log2(opacity): it starts the exponent's fma chain, so v_exp_f32 returns alpha itself
       s_geo[lane][1] = make_float4(Bx, By, FULL ? al : -__log2f(al), __int_as_float(mask));
       if (FULL) s_geo[lane][2] = make_float4(ax, ay, isx, isy);
@@ -198,7 +205,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         if (!(mask & (1 << b))) continue;  // scalar branch
-        const float dx = Xf[b] - g0v.x, dy = Yf[b] - g0v.y;
+        const float dx = FULL ? Xf[b] - g0v.x : 0.0f, dy = FULL ? Yf[b] - g0v.y : 0.0f;
         float p, alpha;
         if (FULL && a.aa) {
           // taichi_lib/generic.py:347-357
@@ -210,7 +217,10 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
           p = 6.28318530717958648f * nx * ny * gs_rcp_fast(dx_ * dy_ * g2v.z * g2v.w);
           alpha = g1v.z * p;
         } else {
-          const float tx = dx * g0v.z + dy * g0v.w, ty = dx * g1v.x + dy * g1v.y;
+          const float tx = FULL ? dx * g0v.z + dy * g0v.w
+                                : __builtin_fmaf(g0v.z, Xf[b], __builtin_fmaf(g0v.w, Yf[b], g0v.x));
+          const float ty = FULL ? dx * g1v.x + dy * g1v.y
+                                : __builtin_fmaf(g1v.x, Xf[b], __builtin_fmaf(g1v.y, Yf[b], g0v.y));
           if (FULL) {
             alpha = g1v.z * gs_exp2_fast(-(tx * tx + ty * ty));
           } else {
