@@ -339,6 +339,16 @@ __device__ __forceinline__ int qc_min_tx(const QueryCache& q) { return int(q.x &
 __device__ __forceinline__ int qc_min_ty(const QueryCache& q) { return int(q.y & 0xfffffu); }
 __device__ __forceinline__ int qc_span_x(const QueryCache& q) { return int((q.x >> 20) & 0x7fu); }
 
+// Does the Gaussian enter the region order at all?  Leaving one out is only allowed when it has no tile here: the exact
+// query decides for a sharded frame (most splats miss a rank's rows, and the sparse exchange lists exactly the ones that
+// do not).  For a whole image nearly every visible Gaussian has a tile, and one that has none simply contributes
+// nothing to the counting pass: the query is skipped (the answer may be conservative, never the other way round).
+__device__ __forceinline__ bool enters_order(const float* g, const MapArgs& a) {
+  if (a.sh.period == 1 && a.sh.begin == 0 && a.sh.end * a.tile_size >= a.Hp) return true;
+  const GridQuery q = grid_query(g, a.Wp, a.Hp, a.tile_size, a.thr);
+  return q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
+}
+
 __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs& a, const RegionGrid& rg) {
   const float ts = float(a.tile_size);
   int tx = int(floorf(g[0] / ts)), ty = int(floorf(g[1] / ts));
@@ -370,8 +380,7 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
     // Gaussians whose candidate span is empty (off-screen within the cull margin; above or below this rank's
     // strip when the frame is sharded) are left out of the ordering, so the counting and bucketing passes never
     // see them.  (A non-empty span whose tiles all fail the OBB test is rare and simply contributes nothing.)
-    const GridQuery q = grid_query(a.points + 7 * i, a.Wp, a.Hp, a.tile_size, a.thr);
-    const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
+    const bool any = enters_order(a.points + 7 * i, a);
     const int r = any ? region_of_gaussian(a.points + 7 * i, a, rg) : -1;
     region_of[i] = r;
     if (r >= 0) atomicAdd(&s_hist[r], 1);
@@ -503,8 +512,7 @@ __global__ __launch_bounds__(BIN) void compact_bin_kernel(GsCompactArgs c, MapAr
       c.indexes[slot] = i;
       // K1 on the row in registers
       const float g[7] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z};
-      const GridQuery q = grid_query(g, a.Wp, a.Hp, a.tile_size, a.thr);
-      const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
+      const bool any = enters_order(g, a);
       const int r = any ? region_of_gaussian(g, a, rg) : -1;
       region_of[slot] = r;
       if (r >= 0) atomicAdd(&s_hist[r], 1);
@@ -670,8 +678,7 @@ __global__ __launch_bounds__(BIN) void project_compact_bin_kernel(gs_proj::ProjA
       c.ndc[slot] = 1.0f - __fdiv_rn(inv_d - c.inv_far, c.ndc_denom);
       c.indexes[slot] = i;
       const float g[7] = {f.u, f.v, f.ax, f.ay, f.s1, f.s2, f.alpha};
-      const GridQuery q = grid_query(g, a.Wp, a.Hp, a.tile_size, a.thr);
-      const bool any = q.span_x > 0 && any_owned_row(a.sh, q.min_ty, q.min_ty + q.span_y);
+      const bool any = enters_order(g, a);
       const int r = any ? region_of_gaussian(g, a, rg) : -1;
       region_of[slot] = r;
       if (r >= 0) atomicAdd(&s_hist[r], 1);
