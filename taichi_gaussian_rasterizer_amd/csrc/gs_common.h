@@ -141,6 +141,7 @@ struct GsCompactArgs {
   void* zero_rows; int zero_row_v4;  // float4 units per row
 };
 int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* stream);
+int gs_map_bin_counters(const GsMapBinPlan* plan, int64_t n, int32_t** words, int32_t* count);
 // experiment (GS_PROJECT_ONE_PASS): projection + cull + compaction + binning in ONE kernel with a decoupled look-back
 // (mapper.hip); pa = project.hip's filled gs_proj::ProjArgs, lookback = gs_map_one_pass_scratch_bytes(n) bytes
 int64_t gs_map_one_pass_scratch_bytes(int64_t n);

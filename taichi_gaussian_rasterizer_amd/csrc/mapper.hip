@@ -357,15 +357,28 @@ __device__ __forceinline__ int region_of_gaussian(const float* g, const MapArgs&
   return (ty / rg.rg) * rg.regions_x + (tx / rg.rg);
 }
 
-// K1: per-workgroup region populations, written to part[region][workgroup] (no global atomics:
-// thousands of workgroups adding into a handful of counters would serialise on one line).
-// BIN Gaussians per workgroup: the part matrix has num_regions * ceil(V / BIN) entries, so a large BIN keeps
-// it (and its scan) small next to the V-entry arrays.
+// K1: per-workgroup region populations.  A workgroup reserves its place inside every region it holds Gaussians of with
+// ONE returning atomic per (workgroup, region) on the region's counter and keeps the offset in part[region][workgroup]
+// (round 3; ~250 atomics per workgroup of 1 024 Gaussians at C3, spread over 256 counters).  The order of the
+// workgroups inside a region is the order their atomics arrive in -- it only decides which counting workgroup a
+// Gaussian lands in, never a result: every tile's bucket is sorted on (depth, index) afterwards.  (Rounds 1 - 2 kept
+// the order deterministic with two scan launches over the part matrix: 5 + 5 us at any size.)
+// region_count must be zero when the pass starts (gs_map_bin_counters).
 constexpr int BIN = 1024;
+// region_count == nullptr: the scan launches follow (K2a / K2b); part[r][b] is the workgroup's own count
+__device__ __forceinline__ void publish_region_hist(const int* s_hist, const RegionGrid& rg, int num_wg, int blk,
+                                                    int* part, int* region_count) {
+  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) {
+    const int h = s_hist[r];
+    if (region_count == nullptr) part[int64_t(r) * num_wg + blk] = h;
+    else if (h > 0) part[int64_t(r) * num_wg + blk] = atomicAdd(region_count + r, h);
+  }
+}
 // The rows of workgroup b are [block_start[b], block_start[b + 1]): b * BIN .. here; the ranges the projection's
 // compaction pass produced when that pass did the binning itself (compact_bin_kernel below).
 __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid rg, int num_wg, int* region_of,
-                                                           int* part, int* touched_blocks, int* block_start) {
+                                                           int* part, int* touched_blocks, int* block_start,
+                                                           int* region_count) {
   __shared__ int s_hist[MAX_REGIONS];
   for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_hist[r] = 0;
   __syncthreads();
@@ -389,15 +402,19 @@ __global__ __launch_bounds__(BIN) void region_count_kernel(MapArgs a, RegionGrid
   // how many of this workgroup's rows are in the ordering at all (gs_map_touched_list compacts them in ascending order)
   const int touched = __syncthreads_count(mine);
   if (threadIdx.x == 0) touched_blocks[blockIdx.x] = touched;
-  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
+  publish_region_hist(s_hist, rg, num_wg, blockIdx.x, part, region_count);
 }
 
+// Two ways from the per-workgroup histograms to "where does workgroup b start inside region r" (part[r][b]), chosen by
+// bin_with_atomics() from the sizes alone:
+//  * few (workgroup, region) pairs (small scenes, a rank's strip): publish_region_hist above -- no launch of its own, and
+//    K3 forms the region starts itself.  At C2 the two scan launches it replaces cost 10 of the mapper's 80 us;
+//  * many (C3: 977 workgroups x 256 regions = 250 k pairs): returning atomics on 256 counters run at ~30 G/s and cost the
+//    binning pass 8 us, more than the scan launches (K2a + K2b, 5 + 5 us at any size) they save.
 // K2a: one workgroup per region: exclusive scan of part[region][*] in place, total -> region_count.
 __global__ __launch_bounds__(1024) void region_part_scan_kernel(int num_wg, int* part, int* region_count,
-                                                                int* tile_hist, int num_tiles) {
+                                                                int) {
   __shared__ int s_wave[16];
-  // also clears the tile histogram the counting pass adds into (saves a memset launch)
-  for (int i = blockIdx.x * 1024 + threadIdx.x; i < num_tiles; i += gridDim.x * 1024) tile_hist[i] = 0;
   int* row = part + int64_t(blockIdx.x) * num_wg;
   int carry = 0;
   for (int base = 0; base < num_wg; base += 1024) {
@@ -432,21 +449,51 @@ __global__ __launch_bounds__(1024) void region_scan_kernel(int num_regions, cons
   }
 }
 
-// K3: write the Gaussian indices grouped by region: position = region start + this workgroup's
-// offset inside the region (K2a) + rank inside the workgroup (LDS atomic).
+// K3: write the Gaussian indices grouped by region: position = region start + this workgroup's offset inside the region
+// (K1's atomic) + rank inside the workgroup (LDS atomic).  The region starts are the exclusive scan of the <= 1 024 region
+// counters, which every workgroup forms for itself in LDS (4 KB out of L2) instead of reading it from a scan launch;
+// workgroup 0 also leaves it -- and the per-region chunk starts (a chunk = up to CHUNK Gaussians of ONE region = one
+// workgroup of the counting / bucketing passes) -- in global memory for those passes, and the whole grid clears the tile
+// histogram the counting pass adds into.
 __global__ __launch_bounds__(BIN) void region_scatter_kernel(RegionGrid rg, int num_wg, const int* region_of,
-                                                             const int* part, const int* region_start,
-                                                             const int* block_start, int* order) {
+                                                             const int* part, const int* region_count,
+                                                             int* region_start, int* chunk_start,
+                                                             const int* block_start, int* order, int* tile_hist,
+                                                             int num_tiles, int scanned) {
   __shared__ int s_cnt[MAX_REGIONS];
-  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) s_cnt[r] = 0;
+  __shared__ int s_start[MAX_REGIONS];
+  __shared__ int s_wave[16];
+  for (int i = blockIdx.x * BIN + threadIdx.x; i < num_tiles; i += gridDim.x * BIN) tile_hist[i] = 0;
+  const int t = threadIdx.x;  // num_regions <= MAX_REGIONS = BIN
+  s_cnt[t] = 0;
+  if (scanned) {  // K2a / K2b have run: the starts are in global memory
+    s_start[t] = t < rg.num_regions ? region_start[t] : 0;
+  } else {
+    const int c = t < rg.num_regions ? region_count[t] : 0;
+    int total_c;
+    const int start = block_exclusive_scan(c, s_wave, total_c);
+    s_start[t] = start;
+    if (blockIdx.x == 0) {
+      int total_ch;
+      const int chunk = block_exclusive_scan((c + CHUNK - 1) / CHUNK, s_wave, total_ch);
+      if (t < rg.num_regions) {
+        region_start[t] = start;
+        chunk_start[t] = chunk;
+      }
+      if (t == 0) {
+        region_start[rg.num_regions] = total_c;
+        chunk_start[rg.num_regions] = total_ch;
+      }
+    }
+  }
   __syncthreads();
   const int first = block_start[blockIdx.x];
-  const int i = first + int(threadIdx.x);
+  const int i = first + t;
   if (i < block_start[blockIdx.x + 1]) {
     const int r = region_of[i];
     if (r >= 0) {
       const int local = atomicAdd(&s_cnt[r], 1);
-      order[region_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = i;
+      order[s_start[r] + part[int64_t(r) * num_wg + blockIdx.x] + local] = i;
     }
   }
 }
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(BIN) void region_scatter_kernel(RegionGrid rg, int 
 // it still holds them in registers, runs K1's query on them.  Frame calls only (gs_project_fwd_ex with a GsMapBinPlan).
 __global__ __launch_bounds__(BIN) void compact_bin_kernel(GsCompactArgs c, MapArgs a, RegionGrid rg, int num_wg,
                                                           int* region_of, int* part, int* touched_blocks,
-                                                          int* block_start) {
+                                                          int* block_start, int* region_count) {
   __shared__ int s_hist[MAX_REGIONS];
   __shared__ int s_cnt[16];
   __shared__ int s_before[16];
@@ -529,11 +576,18 @@ __global__ __launch_bounds__(BIN) void compact_bin_kernel(GsCompactArgs c, MapAr
       *c.num_visible = first + mine_total;
     }
   }
-  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blockIdx.x] = s_hist[r];
+  // the returning atomics of publish_region_hist are issued first and their results stored last: the zero fill of the
+  // gradient rows -- a third of this pass's traffic -- runs underneath their latency (num_regions <= BIN: one region
+  // per thread)
+  const int my_hist = int(threadIdx.x) < rg.num_regions ? s_hist[threadIdx.x] : 0;
+  int my_offset = my_hist;
+  if (region_count != nullptr && my_hist > 0) my_offset = atomicAdd(region_count + threadIdx.x, my_hist);
   if (c.zero_rows) {  // the frame's gradient rows, cleared by the pass that streams the V rows anyway (project.hip)
     float4* dst = static_cast<float4*>(c.zero_rows) + int64_t(first) * c.zero_row_v4;
     for (int e = threadIdx.x; e < mine_total * c.zero_row_v4; e += BIN) dst[e] = make_float4(0, 0, 0, 0);
   }
+  if (int(threadIdx.x) < rg.num_regions && (region_count == nullptr || my_hist > 0))
+    part[int64_t(threadIdx.x) * num_wg + blockIdx.x] = my_offset;
 }
 
 // One pass: projection + cull + stable compaction + K1 (experiment, GS_PROJECT_ONE_PASS).  The visible
@@ -579,8 +633,8 @@ template <bool LOOKBACK>
 __global__ __launch_bounds__(BIN) void project_compact_bin_kernel(gs_proj::ProjArgs pa, GsCompactArgs c, MapArgs a,
                                                                   RegionGrid rg, int num_wg, int* region_of, int* part,
                                                                   int* touched_blocks, int* block_start,
-                                                                  unsigned long long* desc, int* ticket, int* failed,
-                                                                  float* cam_out) {
+                                                                  int* region_count, unsigned long long* desc,
+                                                                  int* ticket, int* failed, float* cam_out) {
   __shared__ int s_hist[MAX_REGIONS];
   __shared__ int s_cnt[16];
   __shared__ int s_scalar[2];
@@ -695,7 +749,7 @@ __global__ __launch_bounds__(BIN) void project_compact_bin_kernel(gs_proj::ProjA
       *c.num_visible = first + mine_total;
     }
   }
-  for (int r = threadIdx.x; r < rg.num_regions; r += BIN) part[int64_t(r) * num_wg + blk] = s_hist[r];
+  publish_region_hist(s_hist, rg, num_wg, blk, part, region_count);
   if (c.zero_rows && ok) {
     float4* dst = static_cast<float4*>(c.zero_rows) + int64_t(first) * c.zero_row_v4;
     for (int e = threadIdx.x; e < mine_total * c.zero_row_v4; e += BIN) dst[e] = make_float4(0, 0, 0, 0);
@@ -1542,6 +1596,22 @@ extern "C" int gs_map_touched_list(int64_t v, const int32_t* v_dev, int64_t num_
   return GS_OK;
 }
 
+// (workgroup, region) pairs up to which the binning pass reserves its places with atomics (see K1 / K2)
+bool bin_with_atomics(int64_t num_wg, const RegionGrid& rg) { return num_wg * rg.num_regions <= (int64_t(1) << 16); }
+
+// the region counters of the plan's mapper scratch: whoever runs in front of the binning pass clears them (the frame
+// calls: the projection's first pass; standalone: a memset)
+int gs_map_bin_counters(const GsMapBinPlan* plan, int64_t n, int32_t** words, int32_t* count) {
+  MapArgs a;
+  if (int rc = fill_args(a, n, nullptr, nullptr, plan->width, plan->height, plan->cfg, 0, plan->shard)) return rc;
+  GS_REQUIRE(a.sh.local_rows > 0 && plan->scratch, GS_ERR_INVALID_ARGUMENT, "gs_map_bin_counters: nothing to bin");
+  const MapScratch m = carve(plan->scratch, n, int64_t(a.tiles_wide) * a.sh.local_rows);
+  const bool atomics = bin_with_atomics(gs_div_up(n > 0 ? n : 1, BIN), make_grid(a));
+  *words = atomics ? m.region_count : nullptr;  // the scan launches write every counter themselves
+  *count = atomics ? MAX_REGIONS + 1 : 0;
+  return GS_OK;
+}
+
 int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* stream) {
   MapArgs a;
   if (int rc = fill_args(a, c->n, c->points, nullptr, plan->width, plan->height, plan->cfg, 0, plan->shard)) return rc;
@@ -1555,7 +1625,8 @@ int gs_map_compact_bin(const GsMapBinPlan* plan, const GsCompactArgs* c, void* s
   const MapScratch m = carve(plan->scratch, c->n, num_tiles);
   const unsigned vb = unsigned(gs_div_up(c->n, BIN));
   hipLaunchKernelGGL(compact_bin_kernel, dim3(vb), dim3(BIN), 0, static_cast<hipStream_t>(stream), *c, a, rg, int(vb),
-                     m.region_of, m.part, m.touched_blocks, m.block_start);
+                     m.region_of, m.part, m.touched_blocks, m.block_start,
+                     bin_with_atomics(vb, rg) ? m.region_count : nullptr);
   GS_CHECK_LAUNCH("gs_map_compact_bin");
   return GS_OK;
 }
@@ -1577,6 +1648,11 @@ int gs_map_project_compact_bin(const GsMapBinPlan* plan, const void* pa, const G
   const MapScratch m = carve(plan->scratch, c->n, num_tiles);
   const unsigned vb = unsigned(gs_div_up(c->n, BIN));
   hipStream_t s = static_cast<hipStream_t>(stream);
+  int* counters = bin_with_atomics(vb, rg) ? m.region_count : nullptr;
+  if (counters && hipMemsetAsync(counters, 0, size_t(MAX_REGIONS + 1) * 4, s) != hipSuccess) {
+    gs_set_error("gs_map_project_compact_bin: hipMemsetAsync failed");
+    return GS_ERR_LAUNCH;
+  }
   if (c->block_offsets == reinterpret_cast<const int*>(1)) {  // variant 2: count, then project again
     GsCompactArgs c2 = *c;
     c2.block_offsets = nullptr;
@@ -1585,7 +1661,7 @@ int gs_map_project_compact_bin(const GsMapBinPlan* plan, const void* pa, const G
                        static_cast<int*>(lookback));
     hipLaunchKernelGGL(project_compact_bin_kernel<false>, dim3(vb), dim3(BIN), 0, s,
                        *static_cast<const gs_proj::ProjArgs*>(pa), c2, a, rg, int(vb), m.region_of, m.part,
-                       m.touched_blocks, m.block_start, nullptr, nullptr, nullptr, camera_pos);
+                       m.touched_blocks, m.block_start, counters, nullptr, nullptr, nullptr, camera_pos);
     GS_CHECK_LAUNCH("gs_map_project_compact_bin");
     return GS_OK;
   }
@@ -1598,7 +1674,7 @@ int gs_map_project_compact_bin(const GsMapBinPlan* plan, const void* pa, const G
   int* ticket = reinterpret_cast<int*>(desc + vb);
   hipLaunchKernelGGL(project_compact_bin_kernel<true>, dim3(vb), dim3(BIN), 0, s,
                      *static_cast<const gs_proj::ProjArgs*>(pa), *c, a, rg, int(vb), m.region_of, m.part,
-                     m.touched_blocks, m.block_start, desc, ticket, ticket + 1, camera_pos);
+                     m.touched_blocks, m.block_start, counters, desc, ticket, ticket + 1, camera_pos);
   GS_CHECK_LAUNCH("gs_map_project_compact_bin");
   return GS_OK;
 }
@@ -1641,15 +1717,24 @@ int gs_map_prepare_ex(int64_t v, const int32_t* v_dev, const float* points, int3
   if (v > 0) {
     GS_REQUIRE(points, GS_ERR_INVALID_ARGUMENT, "gs_map_prepare: points is NULL");
     const unsigned vb = unsigned(gs_div_up(v, BIN));
-    if (!binned)
+    const bool atomics = bin_with_atomics(vb, rg);
+    if (!binned) {
+      if (atomics && hipMemsetAsync(m.region_count, 0, size_t(MAX_REGIONS + 1) * 4, s) != hipSuccess) {
+        gs_set_error("gs_map_prepare: hipMemsetAsync failed");
+        return GS_ERR_LAUNCH;
+      }
       hipLaunchKernelGGL(region_count_kernel, dim3(vb), dim3(BIN), 0, s, a, rg, int(vb), m.region_of, m.part,
-                         m.touched_blocks, m.block_start);
-    hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
-                       m.region_count, hist, num_tiles);
-    hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count, m.region_start,
-                       m.chunk_start);
+                         m.touched_blocks, m.block_start, atomics ? m.region_count : nullptr);
+    }
+    if (!atomics) {
+      hipLaunchKernelGGL(region_part_scan_kernel, dim3(rg.num_regions), dim3(1024), 0, s, int(vb), m.part,
+                         m.region_count, 0);
+      hipLaunchKernelGGL(region_scan_kernel, dim3(1), dim3(1024), 0, s, rg.num_regions, m.region_count,
+                         m.region_start, m.chunk_start);
+    }
     hipLaunchKernelGGL(region_scatter_kernel, dim3(vb), dim3(BIN), 0, s, rg, int(vb), m.region_of, m.part,
-                       m.region_start, m.block_start, m.order);
+                       m.region_count, m.region_start, m.chunk_start, m.block_start, m.order, hist, num_tiles,
+                       atomics ? 0 : 1);
     // one workgroup per chunk of <= CHUNK Gaussians of one region; surplus workgroups exit at once
     hipLaunchKernelGGL(count_binned_kernel, dim3(unsigned(gs_div_up(v, CHUNK)) + unsigned(rg.num_regions)), dim3(CHUNK),
                        size_t(rg.win) * rg.win * 4, s, a, rg, m.order,

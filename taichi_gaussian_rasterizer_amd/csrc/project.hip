@@ -21,10 +21,15 @@ namespace {
 using namespace gs_proj;
 
 // pass 1: project everything, stage rows, count visible per block
-__global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_rows, int* block_counts, float* cam_out) {
+// zero_words: the tile mapper's region counters, which the compaction pass adds into when it also does the mapper's
+// binning (frame calls): cleared here, one pass earlier, instead of by a memset launch
+__global__ __launch_bounds__(256) void project_kernel(ProjArgs a, float4* st_rows, int* block_counts, float* cam_out,
+                                                      int* zero_words, int zero_count) {
   __shared__ int s_cnt[4];
   const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
   if (cam_out && blockIdx.x == 0 && threadIdx.x == 0) camera_position(a.T44, cam_out);
+  if (zero_words && blockIdx.x == 0)
+    for (int e = threadIdx.x; e < zero_count; e += 256) zero_words[e] = 0;
   bool vis = false;
   if (i < a.n) {
     const Cam c = load_cam(a.T44, a.proj);
@@ -365,7 +370,11 @@ int gs_project_fwd_ex(int64_t n, const float* position, const float* log_scaling
     return gs_map_project_compact_bin(bin, &a, &c, camera_pos, scratch, stream);
   }
 #endif
-  hipLaunchKernelGGL(project_kernel, dim3(nb), dim3(256), 0, s, a, st_rows, counts, camera_pos);
+  int32_t* zero_words = nullptr;
+  int32_t zero_count = 0;
+  if (bin)
+    if (int rc = gs_map_bin_counters(bin, n, &zero_words, &zero_count)) return rc;
+  hipLaunchKernelGGL(project_kernel, dim3(nb), dim3(256), 0, s, a, st_rows, counts, camera_pos, zero_words, zero_count);
   GS_CHECK_LAUNCH("gs_project_fwd/project");
   // up to 16384 workgroups (4M Gaussians) each workgroup adds up the counts in front of it (<= 64 KB out of
   // L2); beyond that the quadratic read volume loses to a proper scan

@@ -1,9 +1,9 @@
 #!/bin/bash
-# as ab_lib.sh, printing named stages:  tools/ab_stage.sh STAGE[,STAGE...] lib_a.so lib_b.so ...
+# as ab_lib.sh, printing named stages:  tools/ab_stage.sh STAGE[,STAGE...] lib_a.so lib_b.so ...   (GS_AB_WORKLOAD=c2|c3|...)
 stage=$1; shift
 for round in 1 2 3; do
   for lib in "$@"; do
-    GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 2>gpurun_out/ab_err.txt | python3 -c "
+    GS_LIB_PATH=$(pwd)/$lib python3 bench.py --no-cpu-baseline --steps 40 --workload ${GS_AB_WORKLOAD:-c3} 2>gpurun_out/ab_err.txt | python3 -c "
 import sys, json
 text = sys.stdin.read()
 try:
