@@ -10,8 +10,10 @@
 // Fused path (gs_map_prepare / gs_map_finish), designed for MI355X rather than around a
 // library radix sort:
 //   bin     : order the Gaussians by the screen region (8x8 tiles; larger when the image has more than
-//             1024 of them) of their centre -- LDS histograms + a per-region scan over workgroups, no
-//             global atomics.
+//             1024 of them) of their centre -- LDS histograms per workgroup of 1024 Gaussians, then either one
+//             returning atomic per (workgroup, region) (small frames: no launch of its own) or a per-region scan
+//             over the workgroups (large frames), and a scatter.  In the frame calls the histogram pass IS the
+//             projection's compaction pass (compact_bin_kernel).
 //   count   : 1 lane per Gaussian, OBB query; overlaps are counted in an LDS window over the
 //             workgroup's region (+ border) and flushed with one atomic per window tile into a T-entry
 //             histogram (scattered 4-B global atomics only reach ~20 G/s on MI355X).
