@@ -105,6 +105,14 @@ struct BwdShape {
 // + 2 result writes more per (tile, splat) put the CU's LDS array at ~170 of the ~200 cycles four SIMDs spend on a
 // splat -- the reduction leaves the VALU port only to queue at the LDS.  (v1, one pass with 8 rows, also costs a wave of
 // occupancy: 1.167 vs 1.137 ms per frame.)
+// The per-splat sums start at zero.  Written as `= 0.0f` the first evaluated sub-block of the unrolled chain initialises
+// them for free -- and every splat whose first sub-block is masked out pays 9 v_mov_b32 (about 5 issue slots per
+// overlap on average, in a kernel bound by VALU issue).  1: the zeros come from LDS instead -- ceil(NACC / 4) ds_read_b128
+// of a 64-byte block of zeros at the head of every splat, on the LDS pipe, their latency under the first sub-block's
+// coordinate / exponent arithmetic -- and every sub-block accumulates.  (Kernels with up to 16 sums per splat.)
+#ifndef GS_BWD_ZERO_LDS
+#define GS_BWD_ZERO_LDS 1
+#endif
 #ifndef GS_BWD_FETCH_AHEAD
 #define GS_BWD_FETCH_AHEAD 1
 #endif
@@ -172,6 +180,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   constexpr float K_EXP = 0.84932180028801904f;  // sqrt(0.5 * log2(e))
   constexpr float IK = 1.0f / K_EXP, IK2 = IK * IK;
 
+  int zero_off = 0;  // see GS_BWD_ZERO_LDS
   for (int g0 = range_x; g0 < range_y; g0 += 64) {
     // all pixels of the region saturated -> nothing further contributes (backward.py:116-118)
     // ... and a saturated 8x8 sub-block takes no gradient from here on (:160,166): masked out before its alphas
@@ -255,10 +264,27 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
 
       float S[NS], gf[FP];
+      if (GS_BWD_ZERO_LDS && !GS_BWD_LDS_REDUCE && NACC <= 16) {
+        // (an opaque byte OFFSET, carried across the loop: an opaque pointer would lose its address space and become a
+        // flat load; re-initialising it per splat would cost the v_mov this is about)
+        asm volatile("" : "+v"(zero_off));
+        const float4* zp = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_tr) + zero_off);
+        float z[16];
 #pragma unroll
-      for (int c = 0; c < NS; ++c) S[c] = 0.0f;
+        for (int q = 0; q < (NACC + 3) / 4; ++q) {
+          const float4 zq = zp[q];
+          z[4 * q] = zq.x; z[4 * q + 1] = zq.y; z[4 * q + 2] = zq.z; z[4 * q + 3] = zq.w;
+        }
 #pragma unroll
-      for (int c = 0; c < FP; ++c) gf[c] = 0.0f;
+        for (int c = 0; c < NS; ++c) S[c] = z[c];
+#pragma unroll
+        for (int c = 0; c < FP; ++c) gf[c] = z[(NS + c) < 16 ? NS + c : 0];
+      } else {
+#pragma unroll
+        for (int c = 0; c < NS; ++c) S[c] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < FP; ++c) gf[c] = 0.0f;
+      }
       bool any_grad = false;  // wave-uniform: some pixel of some sub-block took a gradient from this splat
 
 #pragma unroll
@@ -556,8 +582,10 @@ template <int NB, int FP, int MODE>
 __global__ __launch_bounds__(64, GS_BWD_WAVES) void raster_bwd_kernel(const BwdArgs a) {
   __shared__ __attribute__((aligned(16))) float smem[BwdShape<FP, MODE>::ARENA_F];
   // transposition buffer of the lean F = 3 reduction (the only shape that uses it)
-  __shared__ __attribute__((aligned(16))) float s_tr_buf[(GS_BWD_LDS_REDUCE && FP == 3 && MODE == 0) ? TR_ROWS * TR_STRIDE : 4];
+  // (GS_BWD_ZERO_LDS, butterfly reduction: the same pointer carries the 64-byte block of zeros instead)
+  __shared__ __attribute__((aligned(16))) float s_tr_buf[(GS_BWD_LDS_REDUCE && FP == 3 && MODE == 0) ? TR_ROWS * TR_STRIDE + 16 : 16];
   float* s_tr = s_tr_buf;
+  if (GS_BWD_ZERO_LDS && !GS_BWD_LDS_REDUCE && threadIdx.x < 16) s_tr_buf[threadIdx.x] = 0.0f;  // read after the first staging barrier
   const int per_tile = a.sub_x * a.sub_y;
   constexpr int RW = NB == 1 ? 8 : 16, RH = NB == 4 ? 16 : 8;  // the wave's pixel region: NB 8x8 sub-blocks
   int tile, quad;
