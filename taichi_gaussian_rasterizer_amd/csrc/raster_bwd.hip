@@ -113,6 +113,12 @@ struct BwdShape {
 #ifndef GS_BWD_ZERO_LDS
 #define GS_BWD_ZERO_LDS 1
 #endif
+// The sub-block masks of the staged splats as four 64-bit ballots in scalar registers (bit j of ballot b: splat j reaches
+// sub-block b, and b is still live): the walk tests them with scalar bit tests only -- no v_readfirstlane per splat, and
+// the branch no longer waits for the splat's LDS record.
+#ifndef GS_BWD_MASK_BALLOTS
+#define GS_BWD_MASK_BALLOTS 1
+#endif
 #ifndef GS_BWD_FETCH_AHEAD
 #define GS_BWD_FETCH_AHEAD 1
 #endif
@@ -194,6 +200,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
     const int cnt = __builtin_amdgcn_readfirstlane(min(64, range_y - g0));
     float ax = 0, ay = 0, isx = 0, isy = 0, al = 0;
     int idx = 0;
+    int staged_mask = 0;
     if (lane < cnt) {
       idx = a.o2p[g0 + lane];
       const float* p = a.points + int64_t(idx) * 7;
@@ -216,6 +223,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         const float r2 = __log2f(al * a.inv_thr) * (FULL ? 1.38629436111989f : 1.0f);
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, r2, float(x0) + 0.5f - mx, float(y0) + 0.5f - my);
       }
+      staged_mask = mask;
       if (FULL && a.aa) {
         // antialiased pdf: the per-pixel code works in the splat's frame (ux, uy) and needs the sigmas and the half
         // pixel in sigma units, not the scaled ellipse frame
@@ -259,9 +267,19 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       }
     };
     if (GS_BWD_FETCH_AHEAD) fetch_record(0);
+    uint64_t reach[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      reach[b] = (GS_BWD_MASK_BALLOTS && ((live >> b) & 1)) ? __ballot((staged_mask >> b) & 1) : 0ull;
     for (int j = 0; j < cnt; ++j) {
       if (!GS_BWD_FETCH_AHEAD) fetch_record(j);
-      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
+      int mask = 0;
+      if (GS_BWD_MASK_BALLOTS) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mask |= int((reach[b] >> j) & 1ull) << b;
+      } else {
+        mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
+      }
 
       float S[NS], gf[FP];
       if (GS_BWD_ZERO_LDS && !GS_BWD_LDS_REDUCE && NACC <= 16) {
