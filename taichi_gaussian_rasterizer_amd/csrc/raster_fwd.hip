@@ -80,6 +80,12 @@ __device__ __forceinline__ void aa_axis(float t, float inv_sigma, float& num, fl
 // MODE 3: lean quantile pass (no blending, no antialias, no statistics: the median-depth pass of renderer.py:203-208);
 // MODE 0: blend only (lean); 1: blend + per-splat visibility (training with pruning statistics);
 // 2: runtime switches for quantile mode / antialias (+ visibility).
+// (Measured with it and not kept: the blend code twice, with and without the v_med3_f32 of min(alpha, clamp_max_alpha)
+// -- which can only bite when the splat's opacity exceeds the clamp -- and a scalar branch per splat on a ballot of
+// (opacity > clamp): 0.258 against 0.215 ms; four copies of the blend code undo the two-register-set pipeline.)
+#ifndef GS_FWD_MASK_BALLOTS
+#define GS_FWD_MASK_BALLOTS 1
+#endif
 template <int NB, int FP, int MODE>
 __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int x0, int y0, int yout0,
                                                 float4 (*s_geo)[(MODE == 2 ? 3 : 2) + (FP + 3) / 4], float* s_vis,
@@ -132,6 +138,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
     }
     if (live == 0) break;
     const int cnt = __builtin_amdgcn_readfirstlane(min(64, range.y - g0));
+    int staged_mask = 0;
     // ---- stage up to 64 splats: lane j <- splat g0 + j
     if (lane < cnt) {
       const int idx = a.o2p[g0 + lane];
@@ -150,6 +157,7 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
         mask = gs_sub_block_mask<NB>(Ax, Ay, Bx, By, __log2f(al * a.inv_thr), float(x0) + 0.5f - mx,
                                      float(y0) + 0.5f - my);
       }
+      staged_mask = mask;
       // Lean modes: the ellipse-frame coordinates of a pixel are tx = A . (X - m) = A . (X - origin) + A . (origin - m):
       // the second term is formed once per (region, splat) here, and a pixel's tx is two fma on its origin-relative
       // centre (|X - origin| < 16: no cancellation beyond what X - m has) instead of two subtractions, a multiply and
@@ -197,10 +205,21 @@ __device__ __forceinline__ void raster_fwd_body(const FwdArgs& a, int tile, int 
           if (4 * q + k < FP) r.f[4 * q + k] = fv[k];
       }
     };
+    // GS_FWD_MASK_BALLOTS: the staged splats' sub-block masks as four scalar ballots (see raster_bwd.hip)
+    uint64_t reach[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+      reach[b] = (GS_FWD_MASK_BALLOTS && ((live >> b) & 1)) ? __ballot((staged_mask >> b) & 1) : 0ull;
     auto blend_splat = [&](int j, const Rec& r) {
       const float4 g0v = r.g0, g1v = r.g1, g2v = FULL ? r.g2 : make_float4(0, 0, 0, 0);
       const float(&feat)[FP] = r.f;
-      const int mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
+      int mask = 0;
+      if (GS_FWD_MASK_BALLOTS) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) mask |= int((reach[b] >> j) & 1ull) << b;
+      } else {
+        mask = __builtin_amdgcn_readfirstlane(__float_as_int(g1v.w)) & live;
+      }
       float vis_sum = 0.0f;
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
