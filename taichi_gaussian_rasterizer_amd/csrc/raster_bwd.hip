@@ -116,6 +116,13 @@ struct BwdShape {
 // The sub-block masks of the staged splats as four 64-bit ballots in scalar registers (bit j of ballot b: splat j reaches
 // sub-block b, and b is still live): the walk tests them with scalar bit tests only -- no v_readfirstlane per splat, and
 // the branch no longer waits for the splat's LDS record.
+// The ninth of the nine per-splat sums does not fit the 8-value butterfly; it went through six fused DPP adds to row 3
+// (gs_wave_reduce_transposed<9>).  1: four DPP adds leave every lane with its ROW's sum, and one lane per row adds that
+// to the splat's total in LDS (ds_add_f32, four lanes on one address): two DPP adds, a move and a select less on the
+// VALU port per (region, splat).
+#ifndef GS_BWD_NINTH_LDS
+#define GS_BWD_NINTH_LDS 1
+#endif
 #ifndef GS_BWD_MASK_BALLOTS
 #define GS_BWD_MASK_BALLOTS 1
 #endif
@@ -149,7 +156,9 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
   float(*s_out)[OUT_STRIDE] = reinterpret_cast<float(*)[OUT_STRIDE]>(smem);
 
   // which value of the per-splat reduction this lane ends up owning (lane-constant; -1 = none)
-  const int my_slot = (NACC <= 16 && (lane & 3) == 0) ? gs_reduce_slot<(NACC <= 16 ? NACC : 1)>(lane) : -1;
+  constexpr bool NINTH_LDS = GS_BWD_NINTH_LDS && NACC == 9 && !GS_BWD_LDS_REDUCE;
+  constexpr int NBUTTERFLY = NINTH_LDS ? 8 : (NACC <= 16 ? NACC : 1);
+  const int my_slot = (NACC <= 16 && (lane & 3) == 0) ? gs_reduce_slot<NBUTTERFLY>(lane) : -1;
   const int lx = lane & 7, ly = lane >> 3;
   // Tr = 1 - (accumulated weight): the transmittance in front of the next splat.  The reference carries the weight W
   // and tests W < saturate_threshold (backward.py:160); Tr > 1 - saturate_threshold is the same test, and every use of
@@ -503,6 +512,19 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           if ((lane & 7) == 0) s_acc[j][lane >> 3] = t;
           if (lane == 60) s_acc[j][8] = x;
           __syncthreads();
+        } else if (NINTH_LDS) {
+          float w8[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c) w8[c] = c < NS ? S[c < NS ? c : 0] : gf[c >= NS ? c - NS : 0];
+          float x = gf[FP - 1];  // value 8
+          x = gs_dpp_add_full<0x128>(x);  // row_ror:8
+          x = gs_dpp_add_full<0x124>(x);  // row_ror:4
+          x = gs_dpp_add_full<0x122>(x);  // row_ror:2
+          x = gs_dpp_add_full<0x121>(x);  // row_ror:1 -> every lane holds its row's sum
+          const float tot = gs_wave_reduce_transposed<8>(w8, lane);
+          if (my_slot >= 0) s_acc[j][my_slot] = tot;
+          if ((lane & 15) == 0)
+            __hip_atomic_fetch_add(&s_acc[j][8], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // 0 at staging
         } else if (NACC <= 16) {
           float vals[NACC <= 16 ? NACC : 1];
 #pragma unroll
