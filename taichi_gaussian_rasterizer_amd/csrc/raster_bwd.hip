@@ -119,7 +119,9 @@ struct BwdShape {
 // The ninth of the nine per-splat sums does not fit the 8-value butterfly; it went through six fused DPP adds to row 3
 // (gs_wave_reduce_transposed<9>).  1: four DPP adds leave every lane with its ROW's sum, and one lane per row adds that
 // to the splat's total in LDS (ds_add_f32, four lanes on one address): two DPP adds, a move and a select less on the
-// VALU port per (region, splat).
+// VALU port per (region, splat).  (Ending the 8-value butterfly the same way, two DPP stages early -- 32 lanes adding
+// four partial sums per value -- is ruinous: 1.05 against 0.62 ms, profiles/r3/ab_butterfly_quarter_lds_add.txt; an LDS
+// float add costs by the lane.)
 #ifndef GS_BWD_NINTH_LDS
 #define GS_BWD_NINTH_LDS 1
 #endif
