@@ -125,6 +125,9 @@ struct BwdShape {
 #ifndef GS_BWD_NINTH_LDS
 #define GS_BWD_NINTH_LDS 1
 #endif
+#ifndef GS_BWD_HIT_EXEC
+#define GS_BWD_HIT_EXEC 1
+#endif
 #ifndef GS_BWD_MASK_BALLOTS
 #define GS_BWD_MASK_BALLOTS 1
 #endif
@@ -367,12 +370,16 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           }
         }
         const float alpha_raw = FULL ? g1v.z * p : p;
-        const bool hit = alpha_raw > a.thr && Tr[b] > tsat;  // backward.py:160,166
-        if (__ballot(hit) == 0ull) continue;
+        const bool over = alpha_raw > a.thr, open = Tr[b] > tsat;
+        const bool hit = over && open;  // backward.py:160,166
+        // (two ballots of plain compares and a scalar AND: a ballot of the conjunction is rebuilt through a VGPR)
+        if ((__ballot(over) & __ballot(open)) == 0ull) continue;
         any_grad = true;
-        // everything below is linear in a_hit (= 0 where the pixel takes nothing from this splat), so one select does
-        // for the weight, the feature gradients and the moments
-        const float a_hit = hit ? alpha_raw : 0.0f;
+        // Everything below is linear in the pixel's alpha and touches nothing but the lane's own sums and state: it runs
+        // under EXEC = the pixels that take something from this splat (a partly empty EXEC costs a wave64 instruction
+        // nothing extra), which saves the select that used to zero alpha for the others.  (GS_BWD_HIT_EXEC = 0: the select.)
+        if (GS_BWD_HIT_EXEC && !hit) continue;
+        const float a_hit = GS_BWD_HIT_EXEC ? alpha_raw : (hit ? alpha_raw : 0.0f);
         const float alc = __builtin_amdgcn_fmed3f(a_hit, a.cmax, -1.0f);  // min(alpha, cmax), one v_med3_f32 (:169)
         float dot = 0.0f;
 #pragma unroll
@@ -383,7 +390,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         const float num = Tr[b] * dot - R[b];
         const float w = alc * Tr[b];
         float alpha_grad = num * gs_rcp_fast(1.0f - alc);
-        if (FULL || HEUR) alpha_grad = hit ? alpha_grad : 0.0f;  // these also use it without the a_hit factor
+        if (!GS_BWD_HIT_EXEC && (FULL || HEUR)) alpha_grad = hit ? alpha_grad : 0.0f;  // used without the a_hit factor
 #pragma unroll
         for (int c = 0; c < FP; ++c) gf[c] += w * gpix[b][c];  // :201
         if (FULL) {
