@@ -292,6 +292,32 @@ __device__ __forceinline__ float gs_wave_reduce_transposed(float (&v)[N], int la
   return d;
 }
 
+// Experiment (GS_BWD_BPERMUTE in raster_bwd.hip): the two swap stages of the 8-value butterfly through the LDS crossbar
+// (ds_bpermute_b32: no LDS memory, but the LDS pipe) instead of v_permlane32/16_swap -- per register pair two selects,
+// one exchange on the other pipe and an add: 3 VALU slots where swap + add take 4.  Measured: 0.70 against 0.61 ms
+// (profiles/r3/ab_butterfly_bpermute.txt) -- six more operations per (region, splat) on the LDS pipe, which the record
+// fetches and the zero reads already use, cost far more than the six VALU slots they free.  Not used.
+__device__ __forceinline__ float gs_wave_reduce_transposed8_bpermute(float (&v)[8], int lane) {
+  const bool up32 = (lane & 32) != 0, up16 = (lane & 16) != 0;
+  const int addr32 = (lane ^ 32) << 2, addr16 = (lane ^ 16) << 2;
+  float a[4], b[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float keep = up32 ? v[i + 4] : v[i], send = up32 ? v[i] : v[i + 4];
+    a[i] = keep + __int_as_float(__builtin_amdgcn_ds_bpermute(addr32, __float_as_int(send)));
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float keep = up16 ? a[i + 2] : a[i], send = up16 ? a[i] : a[i + 2];
+    b[i] = keep + __int_as_float(__builtin_amdgcn_ds_bpermute(addr16, __float_as_int(send)));
+  }
+  const float t = gs_dpp_add_full<0x128>(b[0]), u = gs_dpp_add_full<0x128>(b[1]);  // row_ror:8
+  float d = gs_dpp_add_full<0x141>((lane & 8) != 0 ? u : t);                      // row_half_mirror
+  d = gs_dpp_add_full<0xB1>(d);                                                   // quad_perm:[1,0,3,2]
+  d = gs_dpp_add_full<0x4E>(d);                                                   // quad_perm:[2,3,0,1]
+  return d;
+}
+
 // N = 9 (six moments + three colour gradients, the lean backward at F = 3): the ninth value would ride the butterfly
 // alone through both swap stages (a v_permlane swap costs 3 plain instructions); six fused DPP adds take it to row 3
 // instead, where lane 60 -- not an owner in the 8-value layout -- picks it up.

@@ -125,6 +125,9 @@ struct BwdShape {
 #ifndef GS_BWD_NINTH_LDS
 #define GS_BWD_NINTH_LDS 1
 #endif
+#ifndef GS_BWD_BPERMUTE
+#define GS_BWD_BPERMUTE 0
+#endif
 #ifndef GS_BWD_HIT_EXEC
 #define GS_BWD_HIT_EXEC 1
 #endif
@@ -530,7 +533,8 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           x = gs_dpp_add_full<0x124>(x);  // row_ror:4
           x = gs_dpp_add_full<0x122>(x);  // row_ror:2
           x = gs_dpp_add_full<0x121>(x);  // row_ror:1 -> every lane holds its row's sum
-          const float tot = gs_wave_reduce_transposed<8>(w8, lane);
+          const float tot = GS_BWD_BPERMUTE ? gs_wave_reduce_transposed8_bpermute(w8, lane)
+                                            : gs_wave_reduce_transposed<8>(w8, lane);
           if (my_slot >= 0) s_acc[j][my_slot] = tot;
           if ((lane & 15) == 0)
             __hip_atomic_fetch_add(&s_acc[j][8], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // 0 at staging
