@@ -321,6 +321,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         for (int c = 0; c < FP; ++c) gf[c] = 0.0f;
       }
       bool any_grad = false;  // wave-uniform: some pixel of some sub-block took a gradient from this splat
+      uint64_t hit_lanes = 0ull;
 
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
@@ -376,8 +377,12 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         const bool over = alpha_raw > a.thr, open = Tr[b] > tsat;
         const bool hit = over && open;  // backward.py:160,166
         // (two ballots of plain compares and a scalar AND: a ballot of the conjunction is rebuilt through a VGPR)
-        if ((__ballot(over) & __ballot(open)) == 0ull) continue;
-        any_grad = true;
+        if (GS_BWD_HIT_EXEC) {
+          hit_lanes |= __ballot(over) & __ballot(open);  // scalar; the EXEC-masked block below skips itself when empty
+        } else {
+          if ((__ballot(over) & __ballot(open)) == 0ull) continue;
+          any_grad = true;
+        }
         // Everything below is linear in the pixel's alpha and touches nothing but the lane's own sums and state: it runs
         // under EXEC = the pixels that take something from this splat (a partly empty EXEC costs a wave64 instruction
         // nothing extra), which saves the select that used to zero alpha for the others.  (GS_BWD_HIT_EXEC = 0: the select.)
@@ -442,6 +447,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
       // first instruction (no second register set, no copies).
       if (GS_BWD_FETCH_AHEAD) fetch_record(min(j + 1, 63));
       // reduce over the wave only if some pixel took a gradient (backward.py:204)
+      if (GS_BWD_HIT_EXEC) any_grad = hit_lanes != 0ull;
       if (any_grad) {
         // transposed butterfly over the wave, sized for the exact number of values; the lane that ends
         // up owning value k stores it (one ds_write_b32 for all values of a chunk)
