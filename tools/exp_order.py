@@ -3,7 +3,8 @@
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import taichi_gaussian_rasterizer_amd as gs
-from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, _native as nv
+from taichi_gaussian_rasterizer_amd import RasterConfig, scenes, fused, _native as nv
+fused.FRAME_CALLS = False  # stage by stage: the per-entry-point timer sees the rasterizer calls
 from taichi_gaussian_rasterizer_amd.mapper.tile_mapper import map_to_tiles
 from taichi_gaussian_rasterizer_amd.rasterizer.function import rasterize_with_tiles
 n, size = 1_000_000, (2048, 2048)
