@@ -75,6 +75,15 @@ __device__ __forceinline__ void s_sig_parts(float z, float& a, float& d) {
   a = gs_rcp_fast(1.0f + e);
   d = __builtin_fmaf(0.21f, z2, 1.6f) * (a * (1.0f - a));
 }
+// ... in two halves: the value alone decides whether a pixel takes anything from the splat; the derivative is only
+// formed for the pixels that do (GS_BWD_HIT_EXEC: under their EXEC mask, skipped when the sub-block has none)
+__device__ __forceinline__ float s_sig_value(float z) {
+  const float e = gs_exp2_fast(z * __builtin_fmaf(-0.07f * 1.44269504088896341f, z * z, -1.6f * 1.44269504088896341f));
+  return gs_rcp_fast(1.0f + e);
+}
+__device__ __forceinline__ float s_sig_slope(float z, float a) {
+  return __builtin_fmaf(0.21f, z * z, 1.6f) * (a * (1.0f - a));
+}
 
 #ifndef GS_BWD_WAVES
 #define GS_BWD_WAVES 1  // minimum waves per SIMD requested from the register allocator (1 = no constraint)
@@ -330,6 +339,7 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         float p, tx = 0, ty = 0;
         float dmx = 0, dmy = 0, dax = 0, day = 0, dsx = 0, dsy = 0;
         float Px = 0, Py = 0;  // antialias: d pdf / d (ux, uy), the splat-frame gradient the mean and axis terms share
+        float aa_z[4] = {0, 0, 0, 0}, aa_a[4] = {0, 0, 0, 0};  // antialias: sigmoid arguments and values
         if (FULL && a.aa) {
           // taichi_lib/generic.py:341-404 in the splat's frame: u = R(axis) d, pdf = tau fx(ux) fy(uy) with
           // f(u; s) = s (S((u + .5) / s) - S((u - .5) / s)).  With a_k = S(z_k), d_k = S'(z_k), z_1,2 = (u +- .5) / s:
@@ -339,23 +349,13 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
           const float ux = dx * axv + dy * ayv, uy = dy * axv - dx * ayv;
           const float zx1 = __builtin_fmaf(ux, g2v.z, g1v.x), zx2 = __builtin_fmaf(ux, g2v.z, -g1v.x);
           const float zy1 = __builtin_fmaf(uy, g2v.w, g1v.y), zy2 = __builtin_fmaf(uy, g2v.w, -g1v.y);
-          float ax1, dx1, ax2, dx2, ay1, dy1, ay2, dy2;
-          s_sig_parts(zx1, ax1, dx1);
-          s_sig_parts(zx2, ax2, dx2);
-          s_sig_parts(zy1, ay1, dy1);
-          s_sig_parts(zy2, ay2, dy2);
-          const float Dx = ax1 - ax2, Dy = ay1 - ay2;
+          aa_z[0] = zx1; aa_z[1] = zx2; aa_z[2] = zy1; aa_z[3] = zy2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) aa_a[k] = s_sig_value(aa_z[k]);
+          const float Dx = aa_a[0] - aa_a[1], Dy = aa_a[2] - aa_a[3];
           const float fx = g0v.z * Dx, fy = g0v.w * Dy;
-          const float tau = 6.28318530717958648f;
-          const float fxt = tau * fx, fyt = tau * fy;
-          p = fx * fyt;
-          Px = (dx1 - dx2) * fyt;
-          Py = fxt * (dy1 - dy2);
-          dsx = (Dx - __builtin_fmaf(zx1, dx1, -(zx2 * dx2))) * fyt;
-          dsy = fxt * (Dy - __builtin_fmaf(zy1, dy1, -(zy2 * dy2)));
-          dax = __builtin_fmaf(Px, dx, Py * dy);
-          day = __builtin_fmaf(Px, dy, -(Py * dx));
-          // dmx, dmy: the wave totals of aag Px, aag Py are rotated out of the frame once per splat (epilogue)
+          p = 6.28318530717958648f * fx * fy;
+          // the derivatives follow behind the hit test (aa_gradients below)
         } else {
           tx = FULL ? dx * g0v.z + dy * g0v.w : __builtin_fmaf(g0v.z, Xf[b], __builtin_fmaf(g0v.w, Yf[b], g0v.x));
           ty = FULL ? dx * g1v.x + dy * g1v.y : __builtin_fmaf(g1v.x, Xf[b], __builtin_fmaf(g1v.y, Yf[b], g0v.y));
@@ -388,6 +388,20 @@ __device__ __forceinline__ void raster_bwd_body(const BwdArgs& a, int tile, int 
         // nothing extra), which saves the select that used to zero alpha for the others.  (GS_BWD_HIT_EXEC = 0: the select.)
         if (GS_BWD_HIT_EXEC && !hit) continue;
         const float a_hit = GS_BWD_HIT_EXEC ? alpha_raw : (hit ? alpha_raw : 0.0f);
+        if (FULL && a.aa) {  // aa_gradients: see the value half above
+          const float d0 = s_sig_slope(aa_z[0], aa_a[0]), d1 = s_sig_slope(aa_z[1], aa_a[1]);
+          const float d2 = s_sig_slope(aa_z[2], aa_a[2]), d3 = s_sig_slope(aa_z[3], aa_a[3]);
+          const float Dx = aa_a[0] - aa_a[1], Dy = aa_a[2] - aa_a[3];
+          const float tau = 6.28318530717958648f;
+          const float fxt = tau * (g0v.z * Dx), fyt = tau * (g0v.w * Dy);
+          Px = (d0 - d1) * fyt;
+          Py = fxt * (d2 - d3);
+          dsx = (Dx - __builtin_fmaf(aa_z[0], d0, -(aa_z[1] * d1))) * fyt;
+          dsy = fxt * (Dy - __builtin_fmaf(aa_z[2], d2, -(aa_z[3] * d3)));
+          dax = __builtin_fmaf(Px, dx, Py * dy);
+          day = __builtin_fmaf(Px, dy, -(Py * dx));
+          // dmx, dmy: the wave totals of aag Px, aag Py are rotated out of the frame once per splat (epilogue)
+        }
         const float alc = __builtin_amdgcn_fmed3f(a_hit, a.cmax, -1.0f);  // min(alpha, cmax), one v_med3_f32 (:169)
         float dot = 0.0f;
 #pragma unroll
